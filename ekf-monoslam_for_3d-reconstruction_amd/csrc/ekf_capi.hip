@@ -1,0 +1,918 @@
+// Host side of libekfslam_hip.so: the filter object (device buffers, feature table, launch
+// sequences) and the C ABI declared in include/ekf_monoslam.h.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ekf_monoslam.h"
+#include "ekf_dense.hpp"
+#include "ekf_kernels.hpp"
+
+namespace ekf {
+
+static thread_local std::string g_create_error;
+
+enum KernelId : int {
+  KID_PREDICT_CAMERA = 0,
+  KID_PROPAGATE_STRIPS,
+  KID_PROPAGATE_STREAMING,
+  KID_MEASURE,
+  KID_INNOVATION,
+  KID_SIGMA_HT,
+  KID_INNOVATION_COV,
+  KID_CHOL_DIAG,
+  KID_CHOL_PANEL,
+  KID_CHOL_TRAILING,
+  KID_STATE_UPDATE,
+  KID_DOWNDATE,
+  KID_NORMALIZE,
+  KID_ADD_FEATURE,
+  KID_COMPACT,
+  KID_MISC,
+  KID_COUNT
+};
+
+static const char* kKernelNames[KID_COUNT] = {
+    "predict_camera",  "propagate_strips", "propagate_streaming", "measure",
+    "innovation",      "sigma_ht",         "innovation_cov",      "chol_diag",
+    "chol_panel",      "chol_trailing",    "state_update",        "downdate_syrk",
+    "normalize_quat",  "add_feature",      "compact_transform",   "misc"};
+
+static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+struct FilterBase {
+  std::string err;
+  virtual ~FilterBase() {}
+  virtual int set_dt(double) = 0;
+  virtual double get_dt() const = 0;
+  virtual int set_stream(void*) = 0;
+  virtual int set_option(int, int) = 0;
+  virtual int synchronize() = 0;
+  virtual int add_feature(double, double) = 0;
+  virtual int remove_features(const int*, int) = 0;
+  virtual int predict(const void*, const void*, int) = 0;
+  virtual int measure() = 0;
+  virtual int get_predictions(void*, unsigned char*, unsigned char*, void*, void*, void*) = 0;
+  virtual int update(const void*, const int*, int, int, bool) = 0;
+  virtual int innovation_covariance(const int*, int, int, void*) = 0;
+  virtual int get_gain(void*) = 0;
+  virtual int last_rows() const = 0;
+  virtual int convert(int index, bool all) = 0;
+  virtual int num_features() const = 0;
+  virtual int state_dim() const = 0;
+  virtual int get_layout(int*, int*) const = 0;
+  virtual int get_state(void*, int, int) = 0;
+  virtual int set_state(const void*, int, int) = 0;
+  virtual int get_sigma(void*, int, int, int, int) = 0;
+  virtual int set_sigma(const void*, int, int, int, int) = 0;
+  virtual int covariance_parameter(double*) = 0;
+  virtual int feature_xyz(int, void*, void*) = 0;
+  virtual int profile_read(int, double*, long long*) = 0;
+  virtual int profile_reset() = 0;
+  virtual void* dev_mu() = 0;
+  virtual void* dev_sigma(int*) = 0;
+};
+
+#define HIPCHK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      char _b[512];                                                                          \
+      snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+               __LINE__);                                                                    \
+      err = _b;                                                                              \
+      return EKF_ERR_DEVICE;                                                                 \
+    }                                                                                        \
+  } while (0)
+
+#define FAIL(code, msg) \
+  do {                  \
+    err = (msg);        \
+    return (code);      \
+  } while (0)
+
+template <typename T>
+struct Filter : FilterBase {
+  ekf_config cfg;
+  CamParams cam;
+  int camera_dim = 14;
+  int capN = 0, cap_n = 0, n_pad = 0, ld = 0;
+  int N = 0, n = 0;
+  int device = 0;
+  double dT = 1.0;                                     // vR.cpp:155
+  double vmax[6];
+  int sigma_pixel_2 = 4;
+  std::vector<int> pos, coding;
+  bool layout_dirty = true;
+  int *d_pos = nullptr, *d_coding = nullptr;
+  T* d_mu[2] = {nullptr, nullptr};
+  int cur_mu = 0;
+  T* d_S[2] = {nullptr, nullptr};
+  int cur = 0;
+  int extent[2] = {0, 0};                              // largest n ever written per Sigma buffer
+  T* d_scr = nullptr;
+  T *d_h = nullptr, *d_Hc = nullptr, *d_Hf = nullptr, *d_Sd = nullptr;
+  unsigned char *d_flags = nullptr, *d_cflag = nullptr;
+  T *d_Jy = nullptr, *d_Yxyz = nullptr;
+  int *d_map_src = nullptr, *d_map_conv = nullptr;
+  // update workspace
+  int m_cap = 0, ldy = 0, y_rows = 0;
+  T* d_Y = nullptr;
+  T* d_Dinv = nullptr;
+  T* d_z = nullptr;
+  int* d_midx = nullptr;
+  int* d_status = nullptr;
+  T* d_tmp = nullptr;                                   // small D2H staging (>= 16 T)
+  T* d_K = nullptr;                                     // lazily allocated gain buffer
+  size_t K_elems = 0;
+  int last_m = 0, last_m_pad = 0, last_n = 0;
+  bool have_meas = false;
+  bool have_update = false;
+  // options
+  int opt_streaming = 0, opt_mfma = 1, opt_profile = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  // profiling
+  struct Pending { int kid; hipEvent_t a, b; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> pool;
+  double prof_ms[KID_COUNT];
+  long long prof_cnt[KID_COUNT];
+
+  static constexpr bool kIsF32 = sizeof(T) == 4;
+  int NB() const { return (kIsF32 && opt_mfma) ? 128 : 64; }
+
+  ~Filter() override {
+    hipSetDevice(device);
+    if (stream) hipStreamSynchronize(stream);
+    for (auto& p : pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (auto e : pool) hipEventDestroy(e);
+    void* ptrs[] = {d_pos, d_coding, d_mu[0], d_mu[1], d_S[0], d_S[1], d_scr, d_h, d_Hc, d_Hf, d_Sd,
+                    d_flags, d_cflag, d_Jy, d_Yxyz, d_map_src, d_map_conv, d_Y, d_Dinv, d_z, d_midx,
+                    d_status, d_tmp, d_K};
+    for (void* p : ptrs) if (p) hipFree(p);
+    if (own_stream && stream) hipStreamDestroy(stream);
+  }
+
+  // ---- profiling helpers ---------------------------------------------------------------
+  bool prof_on(int kid) const {
+    if (opt_profile >= 2) return true;
+    if (opt_profile == 1)
+      return kid == KID_DOWNDATE || kid == KID_PROPAGATE_STREAMING || kid == KID_PROPAGATE_STRIPS ||
+             kid == KID_SIGMA_HT;
+    return false;
+  }
+  hipEvent_t get_event() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+  }
+  struct Scope {
+    Filter* f; int kid; hipEvent_t a = nullptr, b = nullptr; bool on;
+    Scope(Filter* f_, int kid_) : f(f_), kid(kid_), on(f_->prof_on(kid_)) {
+      if (on) { a = f->get_event(); b = f->get_event(); hipEventRecord(a, f->stream); }
+    }
+    ~Scope() {
+      if (on) { hipEventRecord(b, f->stream); f->pending.push_back({kid, a, b}); }
+    }
+  };
+  void resolve_profile() {
+    if (pending.empty()) return;
+    hipStreamSynchronize(stream);
+    for (auto& p : pending) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { prof_ms[p.kid] += ms; prof_cnt[p.kid] += 1; }
+      pool.push_back(p.a); pool.push_back(p.b);
+    }
+    pending.clear();
+  }
+
+  // ---- construction ---------------------------------------------------------------------
+  int init(const ekf_config* c, int cdim, int capacity, int dev) {
+    cfg = *c;
+    camera_dim = cdim;
+    device = dev;
+    capN = capacity;
+    cap_n = camera_dim + 6 * capN;
+    n_pad = round_up(cap_n, 128);
+    ld = n_pad;
+    m_cap = 2 * capN + 3;
+    ldy = round_up(m_cap, 128);
+    y_rows = ldy + n_pad + 128;
+    memset(prof_ms, 0, sizeof(prof_ms));
+    memset(prof_cnt, 0, sizeof(prof_cnt));
+    cam.fx = c->fx; cam.fy = c->fy; cam.u0 = c->u0; cam.v0 = c->v0;
+    cam.k1 = c->k1; cam.k2 = c->k2; cam.k3 = c->k3; cam.p1 = c->p1; cam.p2 = c->p2;
+    cam.width = c->image_width; cam.height = c->image_height; cam.half_window = c->window_size / 2;
+    sigma_pixel_2 = c->sigma_pixel * c->sigma_pixel;               // ints, vR.cpp:150-151
+    const float sv[6] = {c->sigma_vx, c->sigma_vy, c->sigma_vz, c->sigma_wx, c->sigma_wy, c->sigma_wz};
+    for (int i = 0; i < 6; ++i) vmax[i] = double(T(sv[i]) * T(sv[i]));  // vR.cpp:194-200
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    own_stream = true;
+    const size_t sig = (size_t)n_pad * ld;
+    HIPCHK(hipMalloc(&d_S[0], sig * sizeof(T)));
+    HIPCHK(hipMalloc(&d_S[1], sig * sizeof(T)));
+    HIPCHK(hipMemsetAsync(d_S[0], 0, sig * sizeof(T), stream));
+    HIPCHK(hipMemsetAsync(d_S[1], 0, sig * sizeof(T), stream));
+    HIPCHK(hipMalloc(&d_mu[0], (size_t)n_pad * sizeof(T)));
+    HIPCHK(hipMalloc(&d_mu[1], (size_t)n_pad * sizeof(T)));
+    HIPCHK(hipMemsetAsync(d_mu[0], 0, (size_t)n_pad * sizeof(T), stream));
+    HIPCHK(hipMemsetAsync(d_mu[1], 0, (size_t)n_pad * sizeof(T), stream));
+    HIPCHK(hipMalloc(&d_scr, SCR_SIZE * sizeof(T)));
+    const size_t cn = (size_t)std::max(capN, 1);
+    HIPCHK(hipMalloc(&d_pos, cn * sizeof(int)));
+    HIPCHK(hipMalloc(&d_coding, cn * sizeof(int)));
+    HIPCHK(hipMalloc(&d_h, cn * 2 * sizeof(T)));
+    HIPCHK(hipMalloc(&d_Hc, cn * 14 * sizeof(T)));
+    HIPCHK(hipMalloc(&d_Hf, cn * 12 * sizeof(T)));
+    HIPCHK(hipMalloc(&d_Sd, cn * 4 * sizeof(T)));
+    HIPCHK(hipMalloc(&d_flags, cn));
+    HIPCHK(hipMalloc(&d_cflag, cn));
+    HIPCHK(hipMalloc(&d_Jy, cn * 18 * sizeof(T)));
+    HIPCHK(hipMalloc(&d_Yxyz, cn * 3 * sizeof(T)));
+    HIPCHK(hipMalloc(&d_map_src, (size_t)n_pad * sizeof(int)));
+    HIPCHK(hipMalloc(&d_map_conv, (size_t)n_pad * sizeof(int)));
+    HIPCHK(hipMalloc(&d_Y, (size_t)y_rows * ldy * sizeof(T)));
+    HIPCHK(hipMemsetAsync(d_Y, 0, (size_t)y_rows * ldy * sizeof(T), stream));
+    HIPCHK(hipMalloc(&d_Dinv, (size_t)(ldy / 64) * 128 * 128 * sizeof(T)));
+    HIPCHK(hipMalloc(&d_z, (size_t)ldy * sizeof(T)));
+    HIPCHK(hipMalloc(&d_midx, cn * sizeof(int)));
+    HIPCHK(hipMalloc(&d_status, 4 * sizeof(int)));
+    HIPCHK(hipMemsetAsync(d_status, 0, 4 * sizeof(int), stream));
+    HIPCHK(hipMalloc(&d_tmp, 64 * sizeof(T)));
+    // mu0 / Sigma0 (vR.cpp:163-180, 211-216)
+    std::vector<T> mu0(camera_dim, T(0));
+    mu0[3] = T(0.0); mu0[4] = T(0.0); mu0[5] = T(-0.707106781); mu0[6] = T(0.707106781);
+    if (camera_dim == 14) mu0[13] = T(1);
+    n = camera_dim;
+    N = 0;
+    HIPCHK(hipMemcpyAsync(d_mu[0], mu0.data(), camera_dim * sizeof(T), hipMemcpyHostToDevice, stream));
+    std::vector<T> S0((size_t)camera_dim * camera_dim, T(0));
+    for (int i = 0; i < camera_dim; ++i) S0[(size_t)i * camera_dim + i] = T(0.0000000004);
+    if (camera_dim == 14) S0[13 * 14 + 13] = T(0.09);
+    const T sv2 = T(0.0004) * T(0.0004);
+    for (int i = 7; i < 13; ++i) S0[(size_t)i * camera_dim + i] = sv2;
+    HIPCHK(hipMemcpy2DAsync(d_S[0], (size_t)ld * sizeof(T), S0.data(), camera_dim * sizeof(T),
+                            camera_dim * sizeof(T), camera_dim, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    extent[0] = n; extent[1] = 0;
+    // the diagonal-block kernel needs > 64 KiB of LDS
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_diag<T, 64>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, diag_lds(64)));
+    if constexpr (kIsF32) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_diag<T, 128>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, diag_lds(128)));
+    }
+    return EKF_OK;
+  }
+  static int diag_lds(int nb) { return 2 * nb * (nb + 1) * (int)sizeof(T); }
+
+  T* S() { return d_S[cur]; }
+  T* mu() { return d_mu[cur_mu]; }
+
+  int sync_layout() {
+    if (!layout_dirty) return EKF_OK;
+    if (N > 0) {
+      HIPCHK(hipMemcpyAsync(d_pos, pos.data(), N * sizeof(int), hipMemcpyHostToDevice, stream));
+      HIPCHK(hipMemcpyAsync(d_coding, coding.data(), N * sizeof(int), hipMemcpyHostToDevice, stream));
+      HIPCHK(hipStreamSynchronize(stream));   // host vectors may change right after
+    }
+    layout_dirty = false;
+    return EKF_OK;
+  }
+
+  int check_status() {
+    int st[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(st, d_status, sizeof(st), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    if (st[0]) {
+      HIPCHK(hipMemsetAsync(d_status, 0, 4 * sizeof(int), stream));
+      FAIL(EKF_ERR_NUMERIC, "innovation covariance is not positive definite (Cholesky pivot <= 0)");
+    }
+    return EKF_OK;
+  }
+
+  // ---- simple accessors -----------------------------------------------------------------
+  int set_dt(double v) override { if (!(v > 0)) FAIL(EKF_ERR_ARG, "dT must be positive"); dT = v; return EKF_OK; }
+  double get_dt() const override { return dT; }
+  int set_stream(void* s) override {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamSynchronize(stream));
+    resolve_profile();
+    if (own_stream) { hipStreamDestroy(stream); own_stream = false; }
+    stream = reinterpret_cast<hipStream_t>(s);
+    return EKF_OK;
+  }
+  int set_option(int o, int v) override {
+    switch (o) {
+      case EKF_OPT_PROPAGATE_STREAMING: opt_streaming = v ? 1 : 0; return EKF_OK;
+      case EKF_OPT_USE_MFMA: opt_mfma = v ? 1 : 0; return EKF_OK;
+      case EKF_OPT_PROFILE: resolve_profile(); opt_profile = v; return EKF_OK;
+      default: FAIL(EKF_ERR_ARG, "unknown option");
+    }
+  }
+  int synchronize() override {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamSynchronize(stream));
+    return check_status();
+  }
+  int num_features() const override { return N; }
+  int state_dim() const override { return n; }
+  int last_rows() const override { return last_m; }
+  int get_layout(int* p, int* c) const override {
+    for (int i = 0; i < N; ++i) { if (p) p[i] = pos[i]; if (c) c[i] = coding[i]; }
+    return EKF_OK;
+  }
+  void* dev_mu() override { return mu(); }
+  void* dev_sigma(int* l) override { if (l) *l = ld; return S(); }
+
+  // ---- a12 add feature --------------------------------------------------------------------
+  int add_feature(double u, double v) override {
+    HIPCHK(hipSetDevice(device));
+    const T uT = T(u), vT = T(v);
+    const T hw = T(cam.half_window);
+    if (!((uT > hw) && (vT > hw) && (uT < T(cam.width) - hw) && (vT < T(cam.height) - hw))) return 0;
+    if (N >= capN) { err = "capacity_features exceeded"; return -EKF_ERR_CAPACITY; }
+    {
+      Scope sc(this, KID_ADD_FEATURE);
+      k_add_prepare<T><<<1, 64, 0, stream>>>(mu(), S(), ld, n, cam, uT, vT, T(cfg.rho_0), T(sigma_pixel_2),
+                                            T(cfg.sigma_rho_0), d_scr);
+      k_add_border<T><<<(n + 255) / 256, 256, 0, stream>>>(S(), ld, n, d_scr);
+    }
+    if (hipGetLastError() != hipSuccess) { err = "add_feature launch failed"; return -EKF_ERR_DEVICE; }
+    pos.push_back(n);
+    coding.push_back(0);
+    N += 1;
+    n += 6;
+    extent[cur] = std::max(extent[cur], n);
+    layout_dirty = true;
+    have_meas = false;
+    return 1;
+  }
+
+  // zero everything of buffer `b` outside the live n x n (up to what was ever written there)
+  int zero_border(int b, int n_live) {
+    const int ext = extent[b];
+    if (ext > n_live) {
+      // rows [n_live, ext): full width; rows [0, n_live): columns [n_live, ext)
+      HIPCHK(hipMemset2DAsync(d_S[b] + (size_t)n_live * ld, (size_t)ld * sizeof(T), 0, (size_t)ext * sizeof(T),
+                              ext - n_live, stream));
+      HIPCHK(hipMemset2DAsync(d_S[b] + n_live, (size_t)ld * sizeof(T), 0, (size_t)(ext - n_live) * sizeof(T),
+                              n_live, stream));
+    }
+    extent[b] = n_live;
+    return EKF_OK;
+  }
+
+  // ---- a13 / a14: one out-of-place pass for a set of removals and conversions -------------
+  int compact(const std::vector<char>& rm, const std::vector<char>& cv) {
+    std::vector<int> msrc, mconv, npos, ncoding;
+    msrc.reserve(n); mconv.reserve(n);
+    for (int i = 0; i < camera_dim; ++i) { msrc.push_back(i); mconv.push_back(-1); }
+    for (int i = 0; i < N; ++i) {
+      if (rm[i]) continue;
+      const int fs = coding[i] ? 3 : 6;
+      npos.push_back((int)msrc.size());
+      if (cv[i]) {
+        for (int e = 0; e < 3; ++e) { msrc.push_back(pos[i]); mconv.push_back(i * 3 + e); }
+        ncoding.push_back(1);
+      } else {
+        for (int e = 0; e < fs; ++e) { msrc.push_back(pos[i] + e); mconv.push_back(-1); }
+        ncoding.push_back(coding[i]);
+      }
+    }
+    const int n_new = (int)msrc.size();
+    HIPCHK(hipMemcpyAsync(d_map_src, msrc.data(), n_new * sizeof(int), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(d_map_conv, mconv.data(), n_new * sizeof(int), hipMemcpyHostToDevice, stream));
+    const int dst = 1 - cur, dmu = 1 - cur_mu;
+    {
+      Scope sc(this, KID_COMPACT);
+      dim3 grid((n_new + 255) / 256, n_new);
+      k_compact_transform<T><<<grid, 256, 0, stream>>>(S(), d_S[dst], ld, n_new, d_map_src, d_map_conv, d_Jy);
+      k_compact_mu<T><<<(n_new + 255) / 256, 256, 0, stream>>>(mu(), d_mu[dmu], n_new, d_map_src, d_map_conv,
+                                                              d_Yxyz);
+    }
+    HIPCHK(hipGetLastError());
+    extent[dst] = std::max(extent[dst], n_new);
+    int rc = zero_border(dst, n_new);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(stream));        // host map vectors go out of scope
+    cur = dst; cur_mu = dmu;
+    pos.swap(npos); coding.swap(ncoding);
+    N = (int)pos.size();
+    n = n_new;
+    layout_dirty = true;
+    have_meas = false;
+    return EKF_OK;
+  }
+
+  int remove_features(const int* idx, int count) override {
+    HIPCHK(hipSetDevice(device));
+    if (count <= 0) return EKF_OK;
+    std::vector<char> rm(N, 0), cv(N, 0);
+    for (int k = 0; k < count; ++k) {
+      if (idx[k] < 0 || idx[k] >= N) FAIL(EKF_ERR_ARG, "feature index out of range");
+      rm[idx[k]] = 1;
+    }
+    return compact(rm, cv);
+  }
+
+  int convert(int index, bool all) override {
+    HIPCHK(hipSetDevice(device));
+    if (!all && (index < 0 || index >= N)) { err = "feature index out of range"; return -EKF_ERR_ARG; }
+    if (N == 0) return 0;
+    int rc = sync_layout();
+    if (rc) return -rc;
+    k_linearity<T><<<(N + 127) / 128, 128, 0, stream>>>(mu(), S(), ld, d_pos, d_coding, N, d_cflag, d_Jy, d_Yxyz, 0);
+    std::vector<unsigned char> fl(N);
+    if (hipMemcpyAsync(fl.data(), d_cflag, N, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess) { err = "linearity flags D2H failed"; return -EKF_ERR_DEVICE; }
+    std::vector<char> rm(N, 0), cv(N, 0);
+    int cnt = 0;
+    for (int i = 0; i < N; ++i) {
+      if (!all && i != index) continue;
+      if (fl[i] && coding[i] == 0) { cv[i] = 1; ++cnt; }
+    }
+    if (cnt == 0) return 0;
+    rc = compact(rm, cv);
+    if (rc) return -rc;
+    return cnt;
+  }
+
+  // ---- a1-a6 predict --------------------------------------------------------------------
+  int launch_measure() {
+    int rc = sync_layout();
+    if (rc) return rc;
+    if (N > 0) {
+      Scope sc(this, KID_MEASURE);
+      k_measure<T><<<(N + 63) / 64, 64, 0, stream>>>(mu(), S(), ld, d_pos, d_coding, N, cam, T(sigma_pixel_2), d_h,
+                                                    d_Hc, d_Hf, d_flags, d_Sd);
+    }
+    HIPCHK(hipGetLastError());
+    have_meas = true;
+    return EKF_OK;
+  }
+
+  int predict(const void* tc, const void* rc_, int vcontrol) override {
+    HIPCHK(hipSetDevice(device));
+    MotionArgs a;
+    a.dT = dT;
+    const T* t = static_cast<const T*>(tc);
+    const T* r = static_cast<const T*>(rc_);
+    for (int i = 0; i < 3; ++i) { a.t_ctl[i] = t ? double(t[i]) : 0.0; a.r_ctl[i] = r ? double(r[i]) : 0.0; }
+    for (int i = 0; i < 6; ++i) a.vdiag[i] = vcontrol ? vmax[i] : double(T(vmax[i]) * T(2));   // vR.cpp:202
+    {
+      Scope sc(this, KID_PREDICT_CAMERA);
+      k_predict_camera<T><<<1, 64, 0, stream>>>(mu(), d_scr, a);
+    }
+    if (opt_streaming) {
+      const int dst = 1 - cur;
+      {
+        Scope sc(this, KID_PROPAGATE_STREAMING);
+        k_propagate_streaming<T><<<n, 256, 0, stream>>>(S(), d_S[dst], ld, n, d_scr + SCR_FT, d_scr + SCR_Q);
+      }
+      extent[dst] = std::max(extent[dst], n);
+      int rc2 = zero_border(dst, n);
+      if (rc2) return rc2;
+      cur = dst;
+    } else {
+      Scope sc(this, KID_PROPAGATE_STRIPS);
+      k_strip_congruence<T, 13><<<(2 * n + 255) / 256, 256, 0, stream>>>(S(), ld, n, 0, d_scr + SCR_FT, d_scr + SCR_Q);
+    }
+    HIPCHK(hipGetLastError());
+    have_update = false;
+    return launch_measure();
+  }
+
+  int measure() override {
+    HIPCHK(hipSetDevice(device));
+    return launch_measure();
+  }
+
+  int get_predictions(void* h, unsigned char* vis, unsigned char* rem, void* s2, void* hc, void* hf) override {
+    HIPCHK(hipSetDevice(device));
+    if (!have_meas) FAIL(EKF_ERR_STATE, "no predictions: call ekf_predict / ekf_measure first");
+    if (N == 0) return EKF_OK;
+    std::vector<unsigned char> fl(N);
+    std::vector<T> sd, vhc, vhf;
+    if (h) HIPCHK(hipMemcpyAsync(h, d_h, (size_t)N * 2 * sizeof(T), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(fl.data(), d_flags, N, hipMemcpyDeviceToHost, stream));
+    if (s2) { sd.resize((size_t)N * 4); HIPCHK(hipMemcpyAsync(sd.data(), d_Sd, sd.size() * sizeof(T), hipMemcpyDeviceToHost, stream)); }
+    if (hc) { vhc.resize((size_t)N * 14); HIPCHK(hipMemcpyAsync(vhc.data(), d_Hc, vhc.size() * sizeof(T), hipMemcpyDeviceToHost, stream)); }
+    if (hf) { vhf.resize((size_t)N * 12); HIPCHK(hipMemcpyAsync(vhf.data(), d_Hf, vhf.size() * sizeof(T), hipMemcpyDeviceToHost, stream)); }
+    HIPCHK(hipStreamSynchronize(stream));
+    for (int i = 0; i < N; ++i) { if (vis) vis[i] = fl[i] & 1; if (rem) rem[i] = (fl[i] >> 1) & 1; }
+    if (s2) {                                    // row-major 2x2 -> column-major
+      T* o = static_cast<T*>(s2);
+      for (int i = 0; i < N; ++i) { o[4 * i] = sd[4 * i]; o[4 * i + 1] = sd[4 * i + 2]; o[4 * i + 2] = sd[4 * i + 1]; o[4 * i + 3] = sd[4 * i + 3]; }
+    }
+    if (hc) { T* o = static_cast<T*>(hc); for (int i = 0; i < N; ++i) for (int a = 0; a < 2; ++a) for (int c = 0; c < 7; ++c) o[14 * i + c * 2 + a] = vhc[14 * i + a * 7 + c]; }
+    if (hf) { T* o = static_cast<T*>(hf); for (int i = 0; i < N; ++i) for (int a = 0; a < 2; ++a) for (int c = 0; c < 6; ++c) o[12 * i + c * 2 + a] = vhf[12 * i + a * 6 + c]; }
+    return EKF_OK;
+  }
+
+  // ---- dense tile GEMM dispatch -----------------------------------------------------------
+  // C[rows x cols] = beta C + alpha A B^T ; rows, cols multiples of the tile.
+  void gemm(const T* A, int lda, const T* B, int ldb, T* C, int ldc, int rows, int cols, int K, T alpha, T beta,
+            int tri, int row_off, int col_off) {
+    if constexpr (kIsF32) {
+      if (opt_mfma) {
+        dim3 grid(cols / 128, rows / 128);
+        k_gemm_nt_mfma<<<grid, 256, 0, stream>>>(A, lda, B, ldb, C, ldc, K, alpha, beta, tri, row_off, col_off);
+        return;
+      }
+    }
+    dim3 grid(cols / 64, rows / 64);
+    k_gemm_nt_valu<T><<<grid, 256, 0, stream>>>(A, lda, B, ldb, C, ldc, K, alpha, beta, tri, row_off, col_off);
+  }
+
+  // W, S (and nu) for a measured set already resident in d_midx / d_z.
+  int build_innovation(int M, int plane, bool with_nu, int* m_out, int* m_pad_out) {
+    const int nb = NB();
+    const int m = 2 * M + (plane ? 3 : 0);
+    const int m_pad = round_up(m, nb);
+    const int npad_live = round_up(n, nb);
+    T* Wp = d_Y + (size_t)ldy * m_pad;
+    T* nu_row = d_Y + (size_t)ldy * (m_pad + npad_live);
+    // pad rows of W (n..npad_live) and the nu block must be zero
+    if (npad_live > n)
+      HIPCHK(hipMemsetAsync(Wp + (size_t)n * ldy, 0, (size_t)(npad_live - n) * ldy * sizeof(T), stream));
+    HIPCHK(hipMemsetAsync(nu_row, 0, (size_t)nb * ldy * sizeof(T), stream));
+    if (with_nu) {
+      Scope sc(this, KID_INNOVATION);
+      k_innovation<T><<<(m_pad + 255) / 256, 256, 0, stream>>>(d_z, d_h, d_midx, M, plane, mu(), nu_row, m_pad);
+    }
+    {
+      Scope sc(this, KID_SIGMA_HT);
+      constexpr int RB = 32;
+      dim3 grid((m_pad / 2 + 255) / 256, (n + RB - 1) / RB);
+      k_sigma_ht<T, RB><<<grid, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane, Wp, ldy,
+                                                m_pad);
+    }
+    {
+      Scope sc(this, KID_INNOVATION_COV);
+      constexpr int KB = 8;
+      dim3 grid((m_pad + 255) / 256, std::max(1, (M + KB - 1) / KB));
+      k_innovation_cov<T, KB><<<grid, 256, 0, stream>>>(Wp, ldy, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane,
+                                                      T(sigma_pixel_2), T(0.00001), d_Y, m_pad);
+    }
+    HIPCHK(hipGetLastError());
+    *m_out = m;
+    *m_pad_out = m_pad;
+    return EKF_OK;
+  }
+
+  // ---- a8-a11 update ---------------------------------------------------------------------
+  int update(const void* z, const int* idx, int M, int plane, bool on_device) override {
+    HIPCHK(hipSetDevice(device));
+    if (M < 0 || M > N) FAIL(EKF_ERR_ARG, "M out of range");
+    if (M == 0 && !plane) return EKF_OK;
+    if (!have_meas) FAIL(EKF_ERR_STATE, "ekf_update needs the h/H of ekf_predict or ekf_measure");
+    if (M > 0 && (!z || !idx)) FAIL(EKF_ERR_ARG, "z / indices are NULL");
+    if (!on_device) {
+      for (int k = 0; k < M; ++k)
+        if (idx[k] < 0 || idx[k] >= N) FAIL(EKF_ERR_ARG, "feature index out of range");
+    }
+    if (M > 0) {
+      const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+      HIPCHK(hipMemcpyAsync(d_z, z, (size_t)2 * M * sizeof(T), kind, stream));
+      HIPCHK(hipMemcpyAsync(d_midx, idx, (size_t)M * sizeof(int), kind, stream));
+    }
+    int m = 0, m_pad = 0;
+    int rc = build_innovation(M, plane, true, &m, &m_pad);
+    if (rc) return rc;
+    const int nb = NB();
+    const int npad_live = round_up(n, nb);
+    const int rows_total = m_pad + npad_live + nb;       // S, W, nu block
+    T* Y = d_Y;
+    // tall blocked right-looking Cholesky: [S; W; nu^T] -> [L; W L^-T; (L^-1 nu)^T]
+    for (int j = 0; j < m_pad; j += nb) {
+      T* Ajj = Y + (size_t)j * ldy + j;
+      T* Dj = d_Dinv + (size_t)(j / nb) * nb * nb;
+      {
+        Scope sc(this, KID_CHOL_DIAG);
+        if (nb == 128) {
+          if constexpr (kIsF32)
+            k_chol_diag<T, 128><<<1, 1024, diag_lds(128), stream>>>(Ajj, ldy, Dj, d_status);
+        } else {
+          k_chol_diag<T, 64><<<1, 1024, diag_lds(64), stream>>>(Ajj, ldy, Dj, d_status);
+        }
+      }
+      const int r0 = j + nb;                              // first row below the diagonal block
+      {
+        Scope sc(this, KID_CHOL_PANEL);                   // P = Y[r0:, j:j+nb] * Linv_jj^T, in place
+        T* P = Y + (size_t)r0 * ldy + j;
+        gemm(P, ldy, Dj, nb, P, ldy, rows_total - r0, nb, nb, T(1), T(0), 0, 0, 0);
+      }
+      if (r0 < m_pad) {
+        Scope sc(this, KID_CHOL_TRAILING);                // Y[r0:, r0:m_pad] -= P P_S^T (lower of S + all of W)
+        const T* P = Y + (size_t)r0 * ldy + j;
+        T* C = Y + (size_t)r0 * ldy + r0;
+        gemm(P, ldy, P, ldy, C, ldy, rows_total - r0, m_pad - r0, nb, T(-1), T(1), 1, r0, r0);
+      }
+    }
+    const T* V = Y + (size_t)m_pad * ldy;
+    const T* yv = Y + (size_t)(m_pad + npad_live) * ldy;
+    {
+      Scope sc(this, KID_STATE_UPDATE);
+      k_state_update<T><<<(n + 3) / 4, 256, 0, stream>>>(mu(), V, ldy, n, yv, m_pad);
+    }
+    {
+      Scope sc(this, KID_DOWNDATE);                       // Sigma -= V V^T (lower tiles + mirror)
+      gemm(V, ldy, V, ldy, S(), ld, npad_live, npad_live, m_pad, T(-1), T(1), 2, 0, 0);
+    }
+    {
+      Scope sc(this, KID_NORMALIZE);
+      k_normalize_quat<T><<<1, 64, 0, stream>>>(mu(), d_scr);
+      k_strip_congruence<T, 4><<<(2 * n + 255) / 256, 256, 0, stream>>>(S(), ld, n, 3, d_scr + SCR_QN,
+                                                                       static_cast<const T*>(nullptr));
+    }
+    HIPCHK(hipGetLastError());
+    last_m = m; last_m_pad = m_pad; last_n = n;
+    have_update = true;
+    have_meas = false;                                    // h/H belong to the pre-update state
+    return EKF_OK;
+  }
+
+  int innovation_covariance(const int* idx, int M, int plane, void* out) override {
+    HIPCHK(hipSetDevice(device));
+    if (M < 0 || M > N) FAIL(EKF_ERR_ARG, "M out of range");
+    if (!have_meas) FAIL(EKF_ERR_STATE, "ekf_innovation_covariance needs ekf_predict / ekf_measure first");
+    const int mm = 2 * M + (plane ? 3 : 0);
+    if (mm == 0) return EKF_OK;
+    for (int k = 0; k < M; ++k)
+      if (idx[k] < 0 || idx[k] >= N) FAIL(EKF_ERR_ARG, "feature index out of range");
+    if (M > 0) HIPCHK(hipMemcpyAsync(d_midx, idx, (size_t)M * sizeof(int), hipMemcpyHostToDevice, stream));
+    int m = 0, m_pad = 0;
+    int rc = build_innovation(M, plane, false, &m, &m_pad);
+    if (rc) return rc;
+    std::vector<T> tmp((size_t)m * m);
+    HIPCHK(hipMemcpy2DAsync(tmp.data(), (size_t)m * sizeof(T), d_Y, (size_t)ldy * sizeof(T), (size_t)m * sizeof(T), m,
+                            hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    T* o = static_cast<T*>(out);
+    for (int r = 0; r < m; ++r)
+      for (int c = 0; c < m; ++c) o[(size_t)c * m + r] = tmp[(size_t)r * m + c];
+    have_update = false;                                  // Y no longer holds the last factorisation
+    return EKF_OK;
+  }
+
+  int get_gain(void* out) override {
+    HIPCHK(hipSetDevice(device));
+    if (!have_update) FAIL(EKF_ERR_STATE, "no update to take the gain from");
+    const int m = last_m, nn = last_n;
+    const size_t need = (size_t)nn * m;
+    if (need > K_elems) {
+      if (d_K) HIPCHK(hipFree(d_K));
+      d_K = nullptr;
+      HIPCHK(hipMalloc(&d_K, need * sizeof(T)));
+      K_elems = need;
+    }
+    const T* V = d_Y + (size_t)last_m_pad * ldy;
+    HIPCHK(hipMemcpy2DAsync(d_K, (size_t)m * sizeof(T), V, (size_t)ldy * sizeof(T), (size_t)m * sizeof(T), nn,
+                            hipMemcpyDeviceToDevice, stream));
+    k_gain_solve<T><<<(nn + 63) / 64, 64, 0, stream>>>(d_K, m, nn, d_Y, ldy, m);
+    std::vector<T> tmp(need);
+    HIPCHK(hipMemcpyAsync(tmp.data(), d_K, need * sizeof(T), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    T* o = static_cast<T*>(out);
+    for (int r = 0; r < nn; ++r)
+      for (int c = 0; c < m; ++c) o[(size_t)c * nn + r] = tmp[(size_t)r * m + c];
+    return EKF_OK;
+  }
+
+  // ---- state / covariance access ------------------------------------------------------------
+  int get_state(void* out, int off, int count) override {
+    HIPCHK(hipSetDevice(device));
+    if (off < 0 || count < 0 || off + count > n) FAIL(EKF_ERR_ARG, "state segment out of range");
+    if (count) HIPCHK(hipMemcpyAsync(out, mu() + off, (size_t)count * sizeof(T), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return check_status();
+  }
+  int set_state(const void* in, int off, int count) override {
+    HIPCHK(hipSetDevice(device));
+    if (off < 0 || count < 0 || off + count > n) FAIL(EKF_ERR_ARG, "state segment out of range");
+    if (count) HIPCHK(hipMemcpyAsync(mu() + off, in, (size_t)count * sizeof(T), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    have_meas = false;
+    return EKF_OK;
+  }
+  int get_sigma(void* out, int r0, int c0, int rows, int cols) override {
+    HIPCHK(hipSetDevice(device));
+    if (r0 < 0 || c0 < 0 || rows < 0 || cols < 0 || r0 + rows > n || c0 + cols > n)
+      FAIL(EKF_ERR_ARG, "covariance block out of range");
+    if (rows == 0 || cols == 0) return EKF_OK;
+    std::vector<T> tmp((size_t)rows * cols);
+    HIPCHK(hipMemcpy2DAsync(tmp.data(), (size_t)cols * sizeof(T), S() + (size_t)r0 * ld + c0, (size_t)ld * sizeof(T),
+                            (size_t)cols * sizeof(T), rows, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    T* o = static_cast<T*>(out);
+    for (int r = 0; r < rows; ++r)
+      for (int c = 0; c < cols; ++c) o[(size_t)c * rows + r] = tmp[(size_t)r * cols + c];
+    return check_status();
+  }
+  int set_sigma(const void* in, int r0, int c0, int rows, int cols) override {
+    HIPCHK(hipSetDevice(device));
+    if (r0 < 0 || c0 < 0 || rows < 0 || cols < 0 || r0 + rows > n || c0 + cols > n)
+      FAIL(EKF_ERR_ARG, "covariance block out of range");
+    if (rows == 0 || cols == 0) return EKF_OK;
+    const T* i = static_cast<const T*>(in);
+    std::vector<T> tmp((size_t)rows * cols);
+    for (int r = 0; r < rows; ++r)
+      for (int c = 0; c < cols; ++c) tmp[(size_t)r * cols + c] = i[(size_t)c * rows + r];
+    HIPCHK(hipMemcpy2DAsync(S() + (size_t)r0 * ld + c0, (size_t)ld * sizeof(T), tmp.data(), (size_t)cols * sizeof(T),
+                            (size_t)cols * sizeof(T), rows, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    have_meas = false;
+    return EKF_OK;
+  }
+  int covariance_parameter(double* out) override {
+    T d[7 * 7];
+    int rc = get_sigma(d, 0, 0, 7, 7);
+    if (rc) return rc;
+    T acc = T(0);
+    acc += d[0] + d[8] + d[16];                          // vR.cpp:854
+    acc += d[32] + d[40] + d[48] + d[24];                // vR.cpp:855
+    *out = double(acc);
+    return EKF_OK;
+  }
+  int feature_xyz(int index, void* xyz, void* cov) override {
+    HIPCHK(hipSetDevice(device));
+    if (index < 0 || index >= N) FAIL(EKF_ERR_ARG, "feature index out of range");
+    k_feature_xyz<T><<<1, 64, 0, stream>>>(mu(), S(), ld, pos[index], coding[index], d_tmp);
+    T o[12];
+    HIPCHK(hipMemcpyAsync(o, d_tmp, sizeof(o), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    T* x = static_cast<T*>(xyz);
+    T* c = static_cast<T*>(cov);
+    if (x) for (int k = 0; k < 3; ++k) x[k] = o[k];
+    if (c) for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) c[b * 3 + a] = o[3 + a * 3 + b];
+    return EKF_OK;
+  }
+  int profile_read(int kid, double* ms, long long* cnt) override {
+    if (kid < 0 || kid >= KID_COUNT) FAIL(EKF_ERR_ARG, "kernel id out of range");
+    hipSetDevice(device);
+    resolve_profile();
+    if (ms) *ms = prof_ms[kid];
+    if (cnt) *cnt = prof_cnt[kid];
+    return EKF_OK;
+  }
+  int profile_reset() override {
+    hipSetDevice(device);
+    resolve_profile();
+    memset(prof_ms, 0, sizeof(prof_ms));
+    memset(prof_cnt, 0, sizeof(prof_cnt));
+    return EKF_OK;
+  }
+};
+
+}  // namespace ekf
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+using ekf::FilterBase;
+
+struct ekf_filter { FilterBase* impl; };
+
+extern "C" {
+
+void ekf_config_default(ekf_config* c) {
+  if (!c) return;
+  memset(c, 0, sizeof(*c));
+  c->sigma_vx = c->sigma_vy = c->sigma_vz = 0.01f;                 // ConfigVSLAM.cpp:27-28
+  c->sigma_wx = c->sigma_wy = c->sigma_wz = 0.01f;
+  c->window_size = 21; c->sigma_pixel = 2;                          // :30-31
+  c->rho_0 = 0.1f; c->sigma_rho_0 = 0.25f;                          // :33-34
+  c->scale = 1; c->T_camera = 0.5f; c->sigma_size = 2;              // :36-40
+  c->nInitFeatures = 5; c->min_features = 30; c->max_features = 100; c->forsePlane = 0;   // :42-47
+  c->kernel_size = 0;
+  c->fx = 592.2860f; c->fy = 584.9968f; c->u0 = 362.1059f; c->v0 = 275.9642f;            // camModel.hpp:22-31
+  c->k1 = -0.3954f; c->k2 = 0.5521f; c->k3 = 0.f; c->p1 = -0.0075f; c->p2 = 0.0140f;
+  c->image_width = 640; c->image_height = 480;
+}
+
+int ekf_abi_version(void) { return EKF_ABI_VERSION; }
+
+int ekf_create(const ekf_config* cfg, int camera_dim, int capacity_features, int dtype, int device,
+               ekf_filter** out) {
+  if (!out) return EKF_ERR_ARG;
+  *out = nullptr;
+  if (!cfg || (camera_dim != 13 && camera_dim != 14) || capacity_features < 0 ||
+      (dtype != EKF_F32 && dtype != EKF_F64)) {
+    ekf::g_create_error = "ekf_create: bad argument";
+    return EKF_ERR_ARG;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    ekf::g_create_error = "ekf_create: no HIP device (this library has no CPU fallback)";
+    return EKF_ERR_DEVICE;
+  }
+  FilterBase* impl = nullptr;
+  int rc;
+  if (dtype == EKF_F32) {
+    auto* f = new ekf::Filter<float>();
+    rc = f->init(cfg, camera_dim, capacity_features, device);
+    impl = f;
+  } else {
+    auto* f = new ekf::Filter<double>();
+    rc = f->init(cfg, camera_dim, capacity_features, device);
+    impl = f;
+  }
+  if (rc != EKF_OK) {
+    ekf::g_create_error = impl->err;
+    delete impl;
+    return rc;
+  }
+  *out = new ekf_filter{impl};
+  return EKF_OK;
+}
+
+void ekf_destroy(ekf_filter* f) {
+  if (!f) return;
+  delete f->impl;
+  delete f;
+}
+
+const char* ekf_last_error(const ekf_filter* f) {
+  if (!f) return ekf::g_create_error.c_str();
+  return f->impl->err.c_str();
+}
+
+#define IMPL_OR_ARG(f) \
+  if (!(f)) return EKF_ERR_ARG
+
+int ekf_set_dt(ekf_filter* f, double dT) { IMPL_OR_ARG(f); return f->impl->set_dt(dT); }
+double ekf_get_dt(const ekf_filter* f) { return f ? f->impl->get_dt() : 0.0; }
+int ekf_set_stream(ekf_filter* f, void* s) { IMPL_OR_ARG(f); return f->impl->set_stream(s); }
+int ekf_set_option(ekf_filter* f, int o, int v) { IMPL_OR_ARG(f); return f->impl->set_option(o, v); }
+int ekf_synchronize(ekf_filter* f) { IMPL_OR_ARG(f); return f->impl->synchronize(); }
+
+int ekf_add_feature(ekf_filter* f, double u, double v) { if (!f) return -EKF_ERR_ARG; return f->impl->add_feature(u, v); }
+int ekf_remove_feature(ekf_filter* f, int index) { IMPL_OR_ARG(f); return f->impl->remove_features(&index, 1); }
+int ekf_remove_features(ekf_filter* f, const int* idx, int count) {
+  IMPL_OR_ARG(f);
+  if (count > 0 && !idx) return EKF_ERR_ARG;
+  return f->impl->remove_features(idx, count);
+}
+
+int ekf_predict(ekf_filter* f, const void* t, const void* r, int vc) { IMPL_OR_ARG(f); return f->impl->predict(t, r, vc); }
+int ekf_measure(ekf_filter* f) { IMPL_OR_ARG(f); return f->impl->measure(); }
+int ekf_get_predictions(ekf_filter* f, void* h, unsigned char* vis, unsigned char* rem, void* s2, void* hc, void* hf) {
+  IMPL_OR_ARG(f);
+  return f->impl->get_predictions(h, vis, rem, s2, hc, hf);
+}
+int ekf_update(ekf_filter* f, const void* z, const int* idx, int M, int plane) {
+  IMPL_OR_ARG(f);
+  return f->impl->update(z, idx, M, plane, false);
+}
+int ekf_update_device(ekf_filter* f, const void* dz, const int* didx, int M, int plane) {
+  IMPL_OR_ARG(f);
+  return f->impl->update(dz, didx, M, plane, true);
+}
+int ekf_innovation_covariance(ekf_filter* f, const int* idx, int M, int plane, void* out) {
+  IMPL_OR_ARG(f);
+  if (!out) return EKF_ERR_ARG;
+  return f->impl->innovation_covariance(idx, M, plane, out);
+}
+int ekf_get_gain(ekf_filter* f, void* out) { IMPL_OR_ARG(f); if (!out) return EKF_ERR_ARG; return f->impl->get_gain(out); }
+int ekf_last_measurement_rows(const ekf_filter* f) { return f ? f->impl->last_rows() : 0; }
+
+int ekf_convert_xyz_if_linear(ekf_filter* f, int index) { if (!f) return -EKF_ERR_ARG; return f->impl->convert(index, false); }
+int ekf_convert_xyz_if_linear_all(ekf_filter* f) { if (!f) return -EKF_ERR_ARG; return f->impl->convert(0, true); }
+
+int ekf_num_features(const ekf_filter* f) { return f ? f->impl->num_features() : 0; }
+int ekf_state_dim(const ekf_filter* f) { return f ? f->impl->state_dim() : 0; }
+int ekf_get_feature_layout(const ekf_filter* f, int* p, int* c) { IMPL_OR_ARG(f); return f->impl->get_layout(p, c); }
+
+int ekf_get_state(ekf_filter* f, void* out, int off, int cnt) { IMPL_OR_ARG(f); if (cnt > 0 && !out) return EKF_ERR_ARG; return f->impl->get_state(out, off, cnt); }
+int ekf_set_state(ekf_filter* f, const void* in, int off, int cnt) { IMPL_OR_ARG(f); if (cnt > 0 && !in) return EKF_ERR_ARG; return f->impl->set_state(in, off, cnt); }
+int ekf_get_sigma_block(ekf_filter* f, void* out, int r0, int c0, int rows, int cols) {
+  IMPL_OR_ARG(f);
+  if (!out) return EKF_ERR_ARG;
+  return f->impl->get_sigma(out, r0, c0, rows, cols);
+}
+int ekf_set_sigma_block(ekf_filter* f, const void* in, int r0, int c0, int rows, int cols) {
+  IMPL_OR_ARG(f);
+  if (!in) return EKF_ERR_ARG;
+  return f->impl->set_sigma(in, r0, c0, rows, cols);
+}
+int ekf_covariance_parameter(ekf_filter* f, double* out) { IMPL_OR_ARG(f); if (!out) return EKF_ERR_ARG; return f->impl->covariance_parameter(out); }
+int ekf_feature_xyz(ekf_filter* f, int index, void* xyz, void* cov) { IMPL_OR_ARG(f); return f->impl->feature_xyz(index, xyz, cov); }
+
+int ekf_profile_kernels(void) { return ekf::KID_COUNT; }
+const char* ekf_profile_kernel_name(int kid) { return (kid >= 0 && kid < ekf::KID_COUNT) ? ekf::kKernelNames[kid] : ""; }
+int ekf_profile_read(ekf_filter* f, int kid, double* ms, long long* cnt) { IMPL_OR_ARG(f); return f->impl->profile_read(kid, ms, cnt); }
+int ekf_profile_reset(ekf_filter* f) { IMPL_OR_ARG(f); return f->impl->profile_reset(); }
+
+void* ekf_device_mu(ekf_filter* f) { return f ? f->impl->dev_mu() : nullptr; }
+void* ekf_device_sigma(ekf_filter* f, int* ld) { return f ? f->impl->dev_sigma(ld) : nullptr; }
+
+}  // extern "C"

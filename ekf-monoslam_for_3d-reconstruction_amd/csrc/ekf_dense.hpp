@@ -1,0 +1,472 @@
+// Dense kernels of the EKF update (a8-a10): W = Sigma H^T from the compact Jacobian,
+// S = H W + R, the tall blocked Cholesky that turns [S; W; nu^T] into [L; V = W L^-T; y^T],
+// the state update mu += V y and the downdate Sigma -= V V^T.
+//
+// Workspace Y (row-major, ldy per row):
+//   rows [0, m_pad)                    S  (m = 2M (+3) live, identity on the padded diagonal)
+//   rows [m_pad, m_pad + n_pad)        W  (row m_pad + i = row i of Sigma H^T; pads zero)
+//   rows [m_pad + n_pad, +NB)          first row nu^T = (z - h)^T, rest zero
+// All pads are multiples of the GEMM tile, and everything outside the live region is kept
+// zero, so the tile kernels carry no edge guards.
+#pragma once
+#include "ekf_math.hpp"
+
+namespace ekf {
+
+// ---------------------------------------------------------------------------------------
+// nu = z - h for the measured list (+ plane rows: 0 - mu[{1,4,6}], vR.cpp:1257-1260).
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_innovation(const T* __restrict__ z, const T* __restrict__ h, const int* __restrict__ midx,
+                             int M, int plane, const T* __restrict__ mu, T* __restrict__ nu, int m_pad) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= m_pad) return;
+  T v = T(0);
+  if (t < 2 * M) {
+    v = z[t] - h[2 * midx[t >> 1] + (t & 1)];
+  } else if (plane && t < 2 * M + 3) {
+    const int e = t - 2 * M;
+    v = -mu[e == 0 ? 1 : (e == 1 ? 4 : 6)];
+  }
+  nu[t] = v;
+}
+
+// ---------------------------------------------------------------------------------------
+// W = Sigma H^T.  Lane = measurement slot k (feature midx[k]); the lane keeps that feature's
+// 2x13 compact Jacobian in registers and walks RB rows of Sigma: per row it needs the 7
+// camera entries (block-uniform -> scalar loads) and its own 6 (3) feature entries, which are
+// contiguous across lanes.  Sigma is read exactly once; W is written as float2 per lane.
+// Slots k in [M, m_pad/2) write zeros / the plane columns (Sigma[:,1], [:,4], [:,6]).
+// ---------------------------------------------------------------------------------------
+template <typename T, int RB>
+__global__ void k_sigma_ht(const T* __restrict__ S, int ld, int n,
+                           const T* __restrict__ Hc, const T* __restrict__ Hf,
+                           const int* __restrict__ pos, const int* __restrict__ coding,
+                           const int* __restrict__ midx, int M, int plane,
+                           T* __restrict__ W, int ldy, int m_pad) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;    // measurement slot
+  const int row0 = blockIdx.y * RB;
+  const int nslots = m_pad / 2;
+  if (k >= nslots) return;
+  const int row1 = min(row0 + RB, n);
+  if (k < M) {
+    const int fi = midx[k];
+    const int p = pos[fi];
+    const int fs = coding[fi] ? 3 : 6;
+    T hc[14], hf[12];
+#pragma unroll
+    for (int t = 0; t < 14; ++t) hc[t] = Hc[(size_t)fi * 14 + t];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) hf[t] = Hf[(size_t)fi * 12 + t];
+    for (int i = row0; i < row1; ++i) {
+      const T* srow = S + (size_t)i * ld;
+      T a0 = T(0), a1 = T(0);
+#pragma unroll
+      for (int t = 0; t < 7; ++t) { const T v = srow[t]; a0 += v * hc[t]; a1 += v * hc[7 + t]; }
+      if (fs == 6) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) { const T v = srow[p + t]; a0 += v * hf[t]; a1 += v * hf[6 + t]; }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { const T v = srow[p + t]; a0 += v * hf[t]; a1 += v * hf[6 + t]; }
+      }
+      T* w = W + (size_t)i * ldy + 2 * k;
+      w[0] = a0; w[1] = a1;
+    }
+  } else {
+    // pad slots: zeros, except the three plane columns that start at column 2M
+    for (int i = row0; i < row1; ++i) {
+      T* w = W + (size_t)i * ldy;
+      for (int c = 2 * k; c < 2 * k + 2; ++c) {
+        T v = T(0);
+        if (plane && c >= 2 * M && c < 2 * M + 3) {
+          const int e = c - 2 * M;
+          v = S[(size_t)i * ld + (e == 0 ? 1 : (e == 1 ? 4 : 6))];
+        }
+        w[c] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// S = H W + R.  Lane = column c of S (coalesced along W rows); a block handles KB measured
+// features.  The 7 camera rows of W stay in registers across the features of the block.
+// blockIdx.y == gridDim.y-1 additionally writes the plane rows and the identity padding.
+// ---------------------------------------------------------------------------------------
+template <typename T, int KB>
+__global__ void k_innovation_cov(const T* __restrict__ W, int ldy,
+                                 const T* __restrict__ Hc, const T* __restrict__ Hf,
+                                 const int* __restrict__ pos, const int* __restrict__ coding,
+                                 const int* __restrict__ midx, int M, int plane, T r_pix, T r_plane,
+                                 T* __restrict__ Sm, int m_pad) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= m_pad) return;
+  const int m = 2 * M + (plane ? 3 : 0);
+  T wc[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) wc[t] = W[(size_t)t * ldy + c];
+  const int k0 = blockIdx.y * KB;
+  for (int k = k0; k < min(k0 + KB, M); ++k) {
+    const int fi = midx[k];
+    const int p = pos[fi];
+    const int fs = coding[fi] ? 3 : 6;
+    const T* hc = Hc + (size_t)fi * 14;
+    const T* hf = Hf + (size_t)fi * 12;
+    T a0 = T(0), a1 = T(0);
+#pragma unroll
+    for (int t = 0; t < 7; ++t) { a0 += hc[t] * wc[t]; a1 += hc[7 + t] * wc[t]; }
+    for (int t = 0; t < fs; ++t) {
+      const T v = W[(size_t)(p + t) * ldy + c];
+      a0 += hf[t] * v; a1 += hf[6 + t] * v;
+    }
+    if (c == 2 * k) a0 += r_pix;
+    if (c == 2 * k + 1) a1 += r_pix;
+    if (c >= m) { a0 = T(0); a1 = T(0); }
+    Sm[(size_t)(2 * k) * ldy + c] = a0;
+    Sm[(size_t)(2 * k + 1) * ldy + c] = a1;
+  }
+  if (blockIdx.y == gridDim.y - 1) {
+    for (int r = 2 * M; r < m_pad; ++r) {
+      T v = T(0);
+      if (r < m) {                      // plane rows: H = e1, e4, e6  -> rows 1, 4, 6 of W
+        const int e = r - 2 * M;
+        if (c < m) v = W[(size_t)(e == 0 ? 1 : (e == 1 ? 4 : 6)) * ldy + c];
+        if (c == r) v += r_plane;
+      } else if (c == r) {
+        v = T(1);                       // identity padding keeps the padded factorisation regular
+      }
+      Sm[(size_t)r * ldy + c] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Generic tile GEMM  C = beta C + alpha A B^T  (A: rows x K, B: cols x K, both K-contiguous),
+// plain VALU, 64x64 tile, 4x4 per lane.  Serves T = double and the non-MFMA option.
+//   tri: 0 = every tile; 1 = skip tiles strictly above the diagonal, the diagonal being
+//        (row_off + i == col_off + j); 2 = as 1 and mirror every strictly-lower tile into
+//        C^T (symmetric rank-K update).
+//   kmode: 0 = full K; 1 = B is lower-triangular in (j,k): k < col_off_k + (bj+1)*64.
+// Dimensions are multiples of 64 (K of 16): no guards.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_gemm_nt_valu(const T* A, int lda, const T* B, int ldb, T* C, int ldc, int K, T alpha, T beta,
+               int tri, int row_off, int col_off) {
+  constexpr int TS = 64, BK = 16;
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  const int grow0 = row_off + bi * TS, gcol0 = col_off + bj * TS;
+  if (tri && grow0 + TS <= gcol0) return;
+  __shared__ T As[BK][TS + 4];
+  __shared__ T Bs[BK][TS + 4];
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int lr = tid >> 2;            // 0..63 row within tile
+  const int lk = (tid & 3) * 4;       // 0,4,8,12
+  const T* Ap = A + (size_t)(bi * TS + lr) * lda + lk;
+  const T* Bp = B + (size_t)(bj * TS + lr) * ldb + lk;
+  T acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = T(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    T av[4], bv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { av[e] = Ap[k0 + e]; bv[e] = Bp[k0 + e]; }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { As[lk + e][lr] = av[e]; Bs[lk + e][lr] = bv[e]; }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BK; ++kk) {
+      T a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+    }
+  }
+  const bool mirror = (tri == 2) && (grow0 >= gcol0 + TS);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = bi * TS + ty * 4 + i;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = bj * TS + tx * 4 + j;
+      T v = alpha * acc[i][j];
+      if (beta != T(0)) v += beta * C[(size_t)r * ldc + c];
+      C[(size_t)r * ldc + c] = v;
+      if (mirror) C[(size_t)(c + col_off - row_off) * ldc + (r + row_off - col_off)] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// f32 MFMA tile GEMM, same contract as k_gemm_nt_valu with a 128x128x32 tile:
+// 256 lanes = 4 waves (2x2), each wave 64x64 = 2x2 v_mfma_f32_32x32x2_f32 accumulators.
+// LDS image per operand: [q = k/4][row][4] 16-byte slots, slot = q*128 + (row ^ q): the
+// ds_write_b128 of 8 lanes that share a row and the ds_read_b128 of 32 lanes that share q
+// are both bank-conflict free.  One ds_read_b128 per operand feeds 4 MFMAs: lane half h of
+// MFMA e multiplies k = 8s + 4h + e, the same permutation on A and B, so the sum is exact.
+// ---------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ void __launch_bounds__(256)
+k_gemm_nt_mfma(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int K, float alpha, float beta,
+               int tri, int row_off, int col_off) {
+  constexpr int TS = 128, BK = 32, NQ = BK / 4;
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  const int grow0 = row_off + bi * TS, gcol0 = col_off + bj * TS;
+  if (tri && grow0 + TS <= gcol0) return;
+  __shared__ f32x4 lds[2 * NQ * TS];          // A image then B image, 32 KiB
+  f32x4* As = lds;
+  f32x4* Bs = lds + NQ * TS;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  // staging: 1024 float4 per operand, 4 per lane; 8 consecutive lanes cover 128 B of a row
+  const float* Ag[4];
+  const float* Bg[4];
+  int sslot[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int idx = tid + 256 * p;
+    const int row = idx >> 3, q = idx & 7;
+    Ag[p] = A + (size_t)(bi * TS + row) * lda + q * 4;
+    Bg[p] = B + (size_t)(bj * TS + row) * ldb + q * 4;
+    sslot[p] = q * TS + (row ^ q);
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int h = lane >> 5, l31 = lane & 31;
+  f32x4 ra[4], rb[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    ra[p] = *reinterpret_cast<const f32x4*>(Ag[p]);
+    rb[p] = *reinterpret_cast<const f32x4*>(Bg[p]);
+  }
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { As[sslot[p]] = ra[p]; Bs[sslot[p]] = rb[p]; }
+    __syncthreads();
+    if (k0 + BK < K) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        ra[p] = *reinterpret_cast<const f32x4*>(Ag[p] + k0 + BK);
+        rb[p] = *reinterpret_cast<const f32x4*>(Bg[p] + k0 + BK);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < BK / 8; ++s) {
+      const int q = 2 * s + h;
+      f32x4 fa[2], fb[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int ar = wr * 64 + t * 32 + l31;
+        const int br = wc * 64 + t * 32 + l31;
+        fa[t] = As[q * TS + (ar ^ q)];
+        fb[t] = Bs[q * TS + (br ^ q)];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    }
+  }
+  // epilogue: acc reg e of lane -> row (e&3) + 8*(e>>2) + 4*h, col l31 of the 32x32 tile
+  const bool mirror = (tri == 2) && (grow0 >= gcol0 + TS);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int rbase = bi * TS + wr * 64 + i * 32;
+      const int c = bj * TS + wc * 64 + j * 32 + l31;
+      float v[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = rbase + (e & 3) + 8 * (e >> 2) + 4 * h;
+        float x = alpha * acc[i][j][e];
+        if (beta != 0.f) x += beta * C[(size_t)r * ldc + c];
+        v[e] = x;
+        C[(size_t)r * ldc + c] = x;
+      }
+      if (mirror) {
+        // 4 consecutive regs are 4 consecutive rows -> one 16-byte store into the transposed tile
+        float* Ct = C + (size_t)(c + col_off - row_off) * ldc + (row_off - col_off);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+          *reinterpret_cast<f32x4*>(Ct + rbase + 8 * g + 4 * h) = o;
+        }
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Diagonal block of the blocked Cholesky: factor the NB x NB block A = L L^T in LDS and
+// produce L^-1 in the same sweep by carrying an identity block under A (the tall matrix
+// [A; I] turns into [L; L^-T]).  Inner blocking 16: (1) a 16x16 factor in registers of one
+// wave, (2) the 16-wide panel by row substitution, (3) a register-tiled rank-16 update.
+// One workgroup of 1024 lanes; `status[0]` is raised when a pivot is not positive.
+// Writes L (lower, zeros above) back to A and L^-1 (row-major, lower) to Dinv.
+// ---------------------------------------------------------------------------------------
+template <typename T, int NB>
+__global__ void __launch_bounds__(1024)
+k_chol_diag(T* __restrict__ Aglob, int ld, T* __restrict__ Dinv, int* __restrict__ status) {
+  constexpr int LDA = NB + 1;
+  constexpr int RT = NB / 32;                      // logical rows per lane in the update
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* a = reinterpret_cast<T*>(smem_raw);           // [2*NB][LDA]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int idx = tid; idx < NB * NB; idx += blockDim.x) {
+    const int i = idx / NB, j = idx % NB;
+    a[i * LDA + j] = Aglob[(size_t)i * ld + j];
+    a[(NB + i) * LDA + j] = (i == j) ? T(1) : T(0);
+  }
+  __syncthreads();
+  for (int K0 = 0; K0 < NB; K0 += 16) {
+    // (1) 16x16 diagonal factor, rows in registers of wave 0 (lanes >= 16 mirror lanes & 15)
+    if (wave == 0) {
+      const int i = lane & 15;
+      T r[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) r[j] = a[(K0 + i) * LDA + K0 + j];
+      bool bad = false;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const T pk = __shfl(r[k], k, 16);
+        if (!(pk > T(0))) bad = true;
+        const T sq = t_sqrt(pk > T(0) ? pk : T(1));
+        const T lik = (i == k) ? sq : r[k] / sq;
+        r[k] = lik;
+#pragma unroll
+        for (int j = k + 1; j < 16; ++j) {
+          const T ljk = __shfl(lik, j, 16);
+          r[j] -= lik * ljk;
+        }
+      }
+      if (bad && lane == 0) status[0] = 1;
+      if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[(K0 + i) * LDA + K0 + j] = (j <= i) ? r[j] : T(0);
+      }
+    }
+    __syncthreads();
+    // logical rows: top rows K0+16..NB-1, then bottom rows NB+0..NB+K0+15  (NB - 16 + 16 = NB)
+    const int ntop = NB - K0 - 16;
+    // (2) panel: p L16^T = y by forward substitution, one logical row per lane
+    if (tid < NB) {
+      const int prow = (tid < ntop) ? (K0 + 16 + tid) : (NB + (tid - ntop));
+      T y[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) y[c] = a[prow * LDA + K0 + c];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        T acc = y[c];
+#pragma unroll
+        for (int k = 0; k < c; ++k) acc -= y[k] * a[(K0 + c) * LDA + K0 + k];
+        y[c] = acc / a[(K0 + c) * LDA + K0 + c];
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a[prow * LDA + K0 + c] = y[c];
+    }
+    __syncthreads();
+    // (3) rank-16 update of columns K0+16.. for every logical row; lane tile = RT rows x 4 cols
+    const int ncg = ntop / 4;                      // column groups of 4
+    const int l32 = tid & 31, cg = tid >> 5;
+    if (cg < ncg) {
+      int prow[RT];
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        const int lr = l32 + 32 * r;
+        prow[r] = (lr < ntop) ? (K0 + 16 + lr) : (NB + (lr - ntop));
+      }
+      const int c0 = K0 + 16 + cg * 4;
+      T acc[RT][4];
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = T(0);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        T pr[RT], pc[4];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) pr[r] = a[prow[r] * LDA + K0 + k];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pc[c] = a[(c0 + c) * LDA + K0 + k];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[r][c] += pr[r] * pc[c];
+      }
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[prow[r] * LDA + c0 + c] -= acc[r][c];
+    }
+    __syncthreads();
+  }
+  for (int idx = tid; idx < NB * NB; idx += blockDim.x) {
+    const int i = idx / NB, j = idx % NB;
+    Aglob[(size_t)i * ld + j] = (j <= i) ? a[i * LDA + j] : T(0);
+    // bottom block holds Z = L^-T (upper): Linv[i][j] = Z[j][i]
+    Dinv[(size_t)i * NB + j] = (j <= i) ? a[(NB + j) * LDA + i] : T(0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// mu[i] += sum_c V[i][c] y[c]   (K nu = V (L^-1 nu)); one wave per row.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_state_update(T* __restrict__ mu, const T* __restrict__ V, int ldy, int n,
+                               const T* __restrict__ y, int m_pad) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const T* v = V + (size_t)row * ldy;
+  T acc = T(0);
+  for (int c = lane; c < m_pad; c += 64) acc += v[c] * y[c];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) mu[row] += acc;
+}
+
+// ---------------------------------------------------------------------------------------
+// Debug/inspection getter: K = V L^-1 by back substitution, one lane per row of K (in place
+// in Kbuf, which starts as a copy of V).  Not on the hot path.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_gain_solve(T* __restrict__ Kbuf, int ldk, int n, const T* __restrict__ L, int ldy, int m) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  T* k = Kbuf + (size_t)row * ldk;
+  for (int c = m - 1; c >= 0; --c) {
+    T acc = k[c];
+    for (int j = c + 1; j < m; ++j) acc -= k[j] * L[(size_t)j * ldy + c];
+    k[c] = acc / L[(size_t)c * ldy + c];
+  }
+}
+
+template <typename T>
+__global__ void k_copy2d(const T* __restrict__ src, int lds_, T* __restrict__ dst, int ldd, int rows, int cols) {
+  const int r = blockIdx.y;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x)
+    if (r < rows) dst[(size_t)r * ldd + c] = src[(size_t)r * lds_ + c];
+}
+
+}  // namespace ekf

@@ -1,0 +1,571 @@
+// HBM-/latency-bound kernels of the EKF hot path: camera motion step, covariance strip
+// propagation (in place and streaming), per-feature measurement + Jacobian, quaternion
+// normalisation strips, add-feature border and the remove/convert compaction pass.
+// Device storage: Sigma row-major, `ld` elements per row, zero outside the live n x n.
+#pragma once
+#include "ekf_math.hpp"
+
+namespace ekf {
+
+// Scratch block (device, T-typed) shared between the small camera kernels.
+enum : int {
+  SCR_FT = 0,         // 13x13 motion Jacobian, row-major
+  SCR_Q = 169,        // 13x13 process noise
+  SCR_QN = 338,       // 4x4 quaternion-normalisation Jacobian
+  SCR_G = 354,        // add-feature: 6x7 d f / d[r,q]
+  SCR_C = 396,        // add-feature: 6x6 corner block
+  SCR_JY = 432,       // convert: up to MAX_CONVERT 3x6 Jacobians (dynamic; separate buffer used)
+  SCR_SIZE = 512
+};
+
+struct MotionArgs {
+  double dT;
+  double t_ctl[3];
+  double r_ctl[3];
+  double vdiag[6];    // Vmax or Vmax_n diagonal (vR.cpp:194-202, 463-473)
+};
+
+// ---------------------------------------------------------------------------------------
+// a2 + a3: Ft, Q and the camera state step.  One lane; ~1k flops.   (vR.cpp:1492-1535, 1575-1589)
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_predict_camera(T* __restrict__ mu, T* __restrict__ scr, MotionArgs a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  T x[13];
+  for (int i = 0; i < 13; ++i) x[i] = mu[i];
+  const T dTt = T(a.dT);
+  T q[4] = {x[3], x[4], x[5], x[6]};
+  T wc[3] = {x[10] + T(a.r_ctl[0]), x[11] + T(a.r_ctl[1]), x[12] + T(a.r_ctl[2])};
+  T hv[3] = {dTt * wc[0], dTt * wc[1], dTt * wc[2]};
+  T h[4];
+  vec2quat(hv, h);
+  T Ft[169];
+  for (int i = 0; i < 169; ++i) Ft[i] = T(0);
+  for (int i = 0; i < 13; ++i) Ft[i * 13 + i] = T(1);
+  // Ft[3:7,3:7] = Upsilon-bar(h)
+  const T hb[16] = {h[0], -h[1], -h[2], -h[3],
+                    h[1],  h[0],  h[3], -h[2],
+                    h[2], -h[3],  h[0],  h[1],
+                    h[3],  h[2], -h[1],  h[0]};
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) Ft[(3 + r) * 13 + 3 + c] = hb[r * 4 + c];
+  // Ft[3:7,10:13] = Upsilon(q) * t2(w, dT); trigonometry in double like the reference (dT is double)
+  const T nw = t_sqrt(wc[0] * wc[0] + wc[1] * wc[1] + wc[2] * wc[2]);
+  const double ang = a.dT * double(nw) / 2.0;
+  const T s = T(sin(ang));
+  const T c = T(cos(ang));
+  const T sinc = (nw == T(0)) ? T(1) : T(2.0 * sin(ang) / (a.dT * double(nw)));
+  T n_w[3] = {T(0), T(0), T(0)};
+  if (nw > T(0)) { n_w[0] = wc[0] / nw; n_w[1] = wc[1] / nw; n_w[2] = wc[2] / nw; }
+  T t2[12];
+  const T a0 = T(-a.dT * 0.5 * double(s));
+  const T half = T(a.dT * 0.5);
+  for (int j = 0; j < 3; ++j) t2[j] = a0 * n_w[j];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      t2[(1 + i) * 3 + j] = half * ((i == j ? sinc : T(0)) + (c - sinc) * n_w[i] * n_w[j]);
+  const T up[16] = {q[0], -q[1], -q[2], -q[3],
+                    q[1],  q[0], -q[3],  q[2],
+                    q[2],  q[3],  q[0], -q[1],
+                    q[3], -q[2],  q[1],  q[0]};
+  for (int r = 0; r < 4; ++r)
+    for (int j = 0; j < 3; ++j) {
+      T acc = T(0);
+      for (int k = 0; k < 4; ++k) acc += up[r * 4 + k] * t2[k * 3 + j];
+      Ft[(3 + r) * 13 + 10 + j] = acc;
+    }
+  for (int i = 0; i < 3; ++i) Ft[i * 13 + 7 + i] = dTt;
+  for (int i = 0; i < 169; ++i) scr[SCR_FT + i] = Ft[i];
+  // Q = Ft[:,7:13] diag(V / dT / dT) Ft[:,7:13]^T
+  T vs[6];
+  for (int k = 0; k < 6; ++k) vs[k] = T(a.vdiag[k]) / dTt / dTt;
+  for (int i = 0; i < 13; ++i)
+    for (int j = 0; j < 13; ++j) {
+      T acc = T(0);
+      for (int k = 0; k < 6; ++k) acc += Ft[i * 13 + 7 + k] * vs[k] * Ft[j * 13 + 7 + k];
+      scr[SCR_Q + i * 13 + j] = acc;
+    }
+  // Predict_State
+  T v[3] = {x[7] + T(a.t_ctl[0]), x[8] + T(a.t_ctl[1]), x[9] + T(a.t_ctl[2])};
+  T w[3] = {x[10] + T(a.r_ctl[0]), x[11] + T(a.r_ctl[1]), x[12] + T(a.r_ctl[2])};
+  T dq[4], qn[4];
+  T wv[3] = {dTt * w[0], dTt * w[1], dTt * w[2]};
+  vec2quat(wv, dq);
+  quat_mul(q, dq, qn);
+  for (int i = 0; i < 3; ++i) mu[i] = x[i] + dTt * v[i];
+  for (int i = 0; i < 4; ++i) mu[3 + i] = qn[i];
+  for (int i = 0; i < 3; ++i) { mu[7 + i] = v[i]; mu[10 + i] = w[i]; }
+}
+
+// ---------------------------------------------------------------------------------------
+// a1 / a11 in place: Sigma <- J Sigma J^T (+Q) for J = identity except a KxK block at (o,o).
+// Only rows/cols o..o+K-1 change: 2 K n elements.  One launch; three disjoint regions.
+//   lane t <  n : column t of the row strip   (rows o..o+K-1, any column outside the block)
+//   lane t >= n : row (t-n) of the column strip
+//   block 0 additionally owns the KxK corner.
+// ---------------------------------------------------------------------------------------
+template <typename T, int K>
+__global__ void k_strip_congruence(T* __restrict__ S, int ld, int n, int o,
+                                   const T* __restrict__ Jm, const T* __restrict__ Qm) {
+  __shared__ T sJ[K * K];
+  for (int i = threadIdx.x; i < K * K; i += blockDim.x) sJ[i] = Jm[i];
+  __syncthreads();
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) {
+    if (t < o || t >= o + K) {             // row strip, column t
+      T x[K], y[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) x[k] = S[(size_t)(o + k) * ld + t];
+#pragma unroll
+      for (int r = 0; r < K; ++r) {
+        T acc = T(0);
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc += sJ[r * K + k] * x[k];
+        y[r] = acc;
+      }
+#pragma unroll
+      for (int r = 0; r < K; ++r) S[(size_t)(o + r) * ld + t] = y[r];
+    }
+  } else if (t < 2 * n) {
+    const int i = t - n;
+    if (i < o || i >= o + K) {             // column strip, row i
+      T x[K], y[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) x[k] = S[(size_t)i * ld + o + k];
+#pragma unroll
+      for (int c = 0; c < K; ++c) {
+        T acc = T(0);
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc += x[k] * sJ[c * K + k];
+        y[c] = acc;
+      }
+#pragma unroll
+      for (int c = 0; c < K; ++c) S[(size_t)i * ld + o + c] = y[c];
+    }
+  }
+  if (blockIdx.x == 0) {                   // corner: J C J^T + Q through LDS
+    __shared__ T sC[K * K];
+    __shared__ T sA[K * K];
+    for (int i = threadIdx.x; i < K * K; i += blockDim.x)
+      sC[i] = S[(size_t)(o + i / K) * ld + o + i % K];
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * K; i += blockDim.x) {
+      const int r = i / K, c = i % K;
+      T acc = T(0);
+      for (int k = 0; k < K; ++k) acc += sJ[r * K + k] * sC[k * K + c];
+      sA[i] = acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * K; i += blockDim.x) {
+      const int r = i / K, c = i % K;
+      T acc = T(0);
+      for (int k = 0; k < K; ++k) acc += sA[r * K + k] * sJ[c * K + k];
+      if (Qm) acc += Qm[i];
+      S[(size_t)(o + r) * ld + o + c] = acc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// a1 streaming: dst = F src F^T + Q out of place, F = blkdiag(Ft13, I).  Reads n^2, writes n^2
+// (the HBM-roofline formulation of P-propagate).  Rows >= 13 are a float4 copy except their
+// first 13 columns; rows < 13 are the row strip.  grid.x = rows, 256 lanes sweep the row.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_propagate_streaming(const T* __restrict__ src, T* __restrict__ dst, int ld, int n,
+                                      const T* __restrict__ Ft, const T* __restrict__ Qm) {
+  constexpr int K = 13;
+  constexpr int V = 16 / sizeof(T);            // elements per 16-byte vector
+  typedef T vec_t __attribute__((ext_vector_type(V)));
+  __shared__ T sF[K * K];
+  for (int i = threadIdx.x; i < K * K; i += blockDim.x) sF[i] = Ft[i];
+  __syncthreads();
+  for (int row = blockIdx.x; row < n; row += gridDim.x) {
+    if (row >= K) {
+      const T* s = src + (size_t)row * ld;
+      T* d = dst + (size_t)row * ld;
+      // vector chunks [16, n): pure copy (16 is the first vector boundary past column 12)
+      const int nv = (n + V - 1) / V;            // ld is padded, reading to the vector end is in-bounds
+      for (int cv = 16 / V + threadIdx.x; cv < nv; cv += blockDim.x)
+        *reinterpret_cast<vec_t*>(d + (size_t)cv * V) = *reinterpret_cast<const vec_t*>(s + (size_t)cv * V);
+      if (threadIdx.x < 16) {                   // columns 0..15: 13 transformed + 3 copied
+        const int c = threadIdx.x;
+        T acc;
+        if (c < K) {
+          acc = T(0);
+#pragma unroll
+          for (int k = 0; k < K; ++k) acc += s[k] * sF[c * K + k];
+        } else {
+          acc = s[c];
+        }
+        d[c] = acc;
+      }
+    }
+  }
+  // rows 0..12: column-parallel strip + corner, handled by the first blocks
+  const int t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int t = t0; t < n; t += gridDim.x * blockDim.x) {
+    T x[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) x[k] = src[(size_t)k * ld + t];
+    if (t >= K) {
+#pragma unroll
+      for (int r = 0; r < K; ++r) {
+        T acc = T(0);
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc += sF[r * K + k] * x[k];
+        dst[(size_t)r * ld + t] = acc;
+      }
+    }
+  }
+  if (blockIdx.x == 0) {
+    __shared__ T sC[K * K];
+    __shared__ T sA[K * K];
+    for (int i = threadIdx.x; i < K * K; i += blockDim.x) sC[i] = src[(size_t)(i / K) * ld + i % K];
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * K; i += blockDim.x) {
+      const int r = i / K, c = i % K;
+      T acc = T(0);
+      for (int k = 0; k < K; ++k) acc += sF[r * K + k] * sC[k * K + c];
+      sA[i] = acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * K; i += blockDim.x) {
+      const int r = i / K, c = i % K;
+      T acc = T(0);
+      for (int k = 0; k < K; ++k) acc += sA[r * K + k] * sF[c * K + k];
+      dst[(size_t)r * ld + c] = acc + Qm[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// a4 / a5 / a6: one lane per feature: h, compact H (2x7 + 2x6), flags, and the 2x2 diagonal
+// block of St.  flags bit0 = visible (vR.cpp:529), bit1 = rho <= 0 (vR.cpp:517-521).
+// Hc: [N][2][7], Hf: [N][2][6] row-major (XYZ features: last 3 columns zero).
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_measure(const T* __restrict__ mu, const T* __restrict__ S, int ld,
+                          const int* __restrict__ pos, const int* __restrict__ coding, int N,
+                          CamParams cam, T r_pix,
+                          T* __restrict__ h_out, T* __restrict__ Hc, T* __restrict__ Hf,
+                          unsigned char* __restrict__ flags, T* __restrict__ Sd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int p = pos[i];
+  const bool xyz = coding[i] != 0;
+  const int fs = xyz ? 3 : 6;
+  const T r[3] = {mu[0], mu[1], mu[2]};
+  const T qc[4] = {mu[3], -mu[4], -mu[5], -mu[6]};   // complement, vR.cpp:493
+  T R[9];
+  quat2rot(qc, R);
+  T f[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+  for (int k = 0; k < fs; ++k) f[k] = mu[p + k];
+  T d[3];
+  T Jf[18];                                          // d(d)/d(feature), 3x6 row-major
+  T scale_r;
+  T hc[14], hf[12];
+  for (int k = 0; k < 14; ++k) hc[k] = T(0);
+  for (int k = 0; k < 12; ++k) hf[k] = T(0);
+  unsigned char fl = 0;
+  if (!xyz) {
+    const T theta = f[3], phi = f[4], ro = f[5];
+    if (ro <= T(0)) {
+      flags[i] = 2;
+      h_out[2 * i] = T(0); h_out[2 * i + 1] = T(0);
+      for (int k = 0; k < 14; ++k) Hc[(size_t)i * 14 + k] = T(0);
+      for (int k = 0; k < 12; ++k) Hf[(size_t)i * 12 + k] = T(0);
+      for (int k = 0; k < 4; ++k) Sd[(size_t)i * 4 + k] = T(0);
+      return;
+    }
+    const T st = t_sin(theta), ct = t_cos(theta), sp = t_sin(phi), cp = t_cos(phi);
+    const T m[3] = {st * cp, -sp, ct * cp};
+    const T ar[3] = {f[0] - r[0], f[1] - r[1], f[2] - r[2]};
+    for (int k = 0; k < 3; ++k) d[k] = ro * ar[k] + m[k];
+    for (int k = 0; k < 18; ++k) Jf[k] = T(0);
+    Jf[0] = ro; Jf[7] = ro; Jf[14] = ro;
+    Jf[3] = ct * cp;   Jf[9] = T(0);  Jf[15] = -st * cp;
+    Jf[4] = -st * sp;  Jf[10] = -cp;  Jf[16] = -ct * sp;
+    Jf[5] = ar[0];     Jf[11] = ar[1]; Jf[17] = ar[2];
+    scale_r = -ro;
+  } else {
+    for (int k = 0; k < 3; ++k) d[k] = f[k] - r[k];
+    for (int k = 0; k < 18; ++k) Jf[k] = T(0);
+    Jf[0] = T(1); Jf[7] = T(1); Jf[14] = T(1);
+    scale_r = T(-1);
+  }
+  T hC[3];
+  mat3_vec(R, d, hC);
+  T hd[2], Jp[6];
+  project_distort(cam, hC, hd, Jp);
+  if (inside_image(cam, hd[0], hd[1]) && hC[2] >= T(0)) fl |= 1;
+  // JR = Jp * R (2x3)
+  T JR[6];
+  for (int a = 0; a < 2; ++a)
+    for (int c = 0; c < 3; ++c)
+      JR[a * 3 + c] = Jp[a * 3 + 0] * R[0 * 3 + c] + Jp[a * 3 + 1] * R[1 * 3 + c] + Jp[a * 3 + 2] * R[2 * 3 + c];
+  T Jq[12];
+  drot_dq_times(qc, d, Jq);                         // d(R(qc) d)/d qc, then * diag(1,-1,-1,-1)
+  for (int a = 0; a < 2; ++a) {
+    for (int c = 0; c < 3; ++c) hc[a * 7 + c] = scale_r * JR[a * 3 + c];
+    for (int c = 0; c < 4; ++c) {
+      T acc = Jp[a * 3 + 0] * Jq[0 * 4 + c] + Jp[a * 3 + 1] * Jq[1 * 4 + c] + Jp[a * 3 + 2] * Jq[2 * 4 + c];
+      hc[a * 7 + 3 + c] = (c == 0) ? acc : -acc;
+    }
+    for (int c = 0; c < fs; ++c)
+      hf[a * 6 + c] = JR[a * 3 + 0] * Jf[0 * 6 + c] + JR[a * 3 + 1] * Jf[1 * 6 + c] + JR[a * 3 + 2] * Jf[2 * 6 + c];
+  }
+  h_out[2 * i] = hd[0];
+  h_out[2 * i + 1] = hd[1];
+  for (int k = 0; k < 14; ++k) Hc[(size_t)i * 14 + k] = hc[k];
+  for (int k = 0; k < 12; ++k) Hf[(size_t)i * 12 + k] = hf[k];
+  flags[i] = fl;
+  // 2x2 block of St: Hrow P Hrow^T + r_pix I with P = Sigma[idx, idx], idx = [0..6, p..p+fs)
+  T t0[13], t1[13];                                  // (P Hrow^T) columns
+  for (int a = 0; a < 13; ++a) {
+    const int ra = (a < 7) ? a : p + (a - 7);
+    T acc0 = T(0), acc1 = T(0);
+    if (a < 7 + fs) {
+      const T* row = S + (size_t)ra * ld;
+      for (int b = 0; b < 7; ++b) { const T v = row[b]; acc0 += v * hc[b]; acc1 += v * hc[7 + b]; }
+      for (int b = 0; b < fs; ++b) { const T v = row[p + b]; acc0 += v * hf[b]; acc1 += v * hf[6 + b]; }
+    }
+    t0[a] = acc0; t1[a] = acc1;
+  }
+  T s00 = T(0), s01 = T(0), s10 = T(0), s11 = T(0);
+  for (int a = 0; a < 7; ++a) {
+    s00 += hc[a] * t0[a]; s01 += hc[a] * t1[a]; s10 += hc[7 + a] * t0[a]; s11 += hc[7 + a] * t1[a];
+  }
+  for (int a = 0; a < fs; ++a) {
+    s00 += hf[a] * t0[7 + a]; s01 += hf[a] * t1[7 + a]; s10 += hf[6 + a] * t0[7 + a]; s11 += hf[6 + a] * t1[7 + a];
+  }
+  Sd[(size_t)i * 4 + 0] = s00 + r_pix;
+  Sd[(size_t)i * 4 + 1] = s01;
+  Sd[(size_t)i * 4 + 2] = s10;
+  Sd[(size_t)i * 4 + 3] = s11 + r_pix;
+}
+
+// ---------------------------------------------------------------------------------------
+// a11: quaternion normalisation: mu[3:7] /= |q|, Qn = (|q|^2 I - q q^T)/|q|^3 -> scratch.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_normalize_quat(T* __restrict__ mu, T* __restrict__ scr) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const T q[4] = {mu[3], mu[4], mu[5], mu[6]};
+  const T nn = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  const T norma = t_sqrt(nn);
+  const T inv3 = T(1) / (norma * norma * norma);
+  for (int i = 0; i < 4; ++i) mu[3 + i] = q[i] / norma;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
+      scr[SCR_QN + i * 4 + j] = ((i == j ? norma * norma : T(0)) - q[i] * q[j]) * inv3;
+}
+
+// ---------------------------------------------------------------------------------------
+// a12 add feature, step 1 (one lane): new 6-vector into mu[n..n+6), G = d f/d[r,q] (6x7),
+// corner C = G Scc G^T + s_pix2 Jp Jp^T + e6 e6^T sigma_rho_0 (6x6).
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_add_prepare(T* __restrict__ mu, const T* __restrict__ S, int ld, int n,
+                              CamParams cam, T u, T v, T rho0, T s_pix2, T sigma_rho0,
+                              T* __restrict__ scr) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const T q[4] = {mu[3], mu[4], mu[5], mu[6]};
+  T hC[3], Jn[4];
+  undistort_deproject(cam, u, v, hC, Jn);
+  T R[9];
+  quat2rot(q, R);
+  T hW[3];
+  mat3_vec(R, hC, hW);
+  const T hx = hW[0], hy = hW[1], hz = hW[2];
+  const T theta = t_atan2(hx, hz);
+  const T phi = t_atan2(-hy, t_sqrt(hx * hx + hz * hz));
+  mu[n + 0] = mu[0]; mu[n + 1] = mu[1]; mu[n + 2] = mu[2];
+  mu[n + 3] = theta; mu[n + 4] = phi; mu[n + 5] = rho0;
+  // J_f_hW rows 3 (theta) and 4 (phi)                             (vR.cpp:1599-1623)
+  const T normal = hx * hx + hz * hz, normal2 = normal + hy * hy, sn = t_sqrt(normal);
+  const T jt[3] = {hz / normal, T(0), -hx / normal};
+  const T jp[3] = {hx * hy / sn / normal2, -sn / normal2, hz * hy / sn / normal2};
+  T Jq[12];
+  drot_dq_times(q, hC, Jq);                                          // d(R(q) hC)/dq
+  T G[42];
+  for (int i = 0; i < 42; ++i) G[i] = T(0);
+  G[0 * 7 + 0] = T(1); G[1 * 7 + 1] = T(1); G[2 * 7 + 2] = T(1);
+  for (int c = 0; c < 4; ++c) {
+    G[3 * 7 + 3 + c] = jt[0] * Jq[0 * 4 + c] + jt[1] * Jq[1 * 4 + c] + jt[2] * Jq[2 * 4 + c];
+    G[4 * 7 + 3 + c] = jp[0] * Jq[0 * 4 + c] + jp[1] * Jq[1 * 4 + c] + jp[2] * Jq[2 * 4 + c];
+  }
+  // Jpix = J_f_hW * R * J_undist (6x2); J_undist = [Jn; 0 0]
+  T RJ[6];                                                           // R * J_undist (3x2)
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 2; ++c) RJ[r * 2 + c] = R[r * 3 + 0] * Jn[0 * 2 + c] + R[r * 3 + 1] * Jn[1 * 2 + c];
+  T Jx[12];
+  for (int i = 0; i < 12; ++i) Jx[i] = T(0);
+  for (int c = 0; c < 2; ++c) {
+    Jx[3 * 2 + c] = jt[0] * RJ[0 * 2 + c] + jt[1] * RJ[1 * 2 + c] + jt[2] * RJ[2 * 2 + c];
+    Jx[4 * 2 + c] = jp[0] * RJ[0 * 2 + c] + jp[1] * RJ[1 * 2 + c] + jp[2] * RJ[2 * 2 + c];
+  }
+  for (int i = 0; i < 42; ++i) scr[SCR_G + i] = G[i];
+  // corner
+  T GS[42];                                                          // G * Scc (6x7)
+  for (int a = 0; a < 6; ++a)
+    for (int c = 0; c < 7; ++c) {
+      T acc = T(0);
+      for (int k = 0; k < 7; ++k) acc += G[a * 7 + k] * S[(size_t)k * ld + c];
+      GS[a * 7 + c] = acc;
+    }
+  for (int a = 0; a < 6; ++a)
+    for (int b = 0; b < 6; ++b) {
+      T acc = T(0);
+      for (int k = 0; k < 7; ++k) acc += GS[a * 7 + k] * G[b * 7 + k];
+      acc += s_pix2 * (Jx[a * 2 + 0] * Jx[b * 2 + 0] + Jx[a * 2 + 1] * Jx[b * 2 + 1]);
+      if (a == 5 && b == 5) acc += sigma_rho0;                       // unsquared, vR.cpp:365
+      scr[SCR_C + a * 6 + b] = acc;
+    }
+}
+
+// a12 step 2: border rows/cols.  lane j < n: Sigma[n+a, j] = sum_t G[a,t] Sigma[t, j],
+// Sigma[j, n+a] = sum_t Sigma[j, t] G[a,t]; block 0 writes the 6x6 corner.
+template <typename T>
+__global__ void k_add_border(T* __restrict__ S, int ld, int n, const T* __restrict__ scr) {
+  __shared__ T sG[42];
+  for (int i = threadIdx.x; i < 42; i += blockDim.x) sG[i] = scr[SCR_G + i];
+  __syncthreads();
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) {
+    T col[7], row[7];
+#pragma unroll
+    for (int t = 0; t < 7; ++t) { col[t] = S[(size_t)t * ld + j]; row[t] = S[(size_t)j * ld + t]; }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      T accr = T(0), accc = T(0);
+#pragma unroll
+      for (int t = 0; t < 7; ++t) { accr += sG[a * 7 + t] * col[t]; accc += row[t] * sG[a * 7 + t]; }
+      S[(size_t)(n + a) * ld + j] = accr;
+      S[(size_t)j * ld + n + a] = accc;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 36)
+    S[(size_t)(n + threadIdx.x / 6) * ld + n + threadIdx.x % 6] = scr[SCR_C + threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------
+// a13 / a14: remove + convert in one out-of-place pass  dst = J src J^T.
+// Each NEW index i' has a descriptor: src[i'] = first old index, conv[i'] = -1 for a
+// pass-through, else (converted feature slot * 3 + component e): the new entry is
+// sum_b Jy[slot][e][b] * old[src + b], b < 6.  Lanes sweep j' (coalesced), blockIdx.y = i'.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_compact_transform(const T* __restrict__ src, T* __restrict__ dst, int ld,
+                                    int n_new, const int* __restrict__ map_src,
+                                    const int* __restrict__ map_conv, const T* __restrict__ Jy) {
+  const int ip = blockIdx.y;
+  const int si = map_src[ip];
+  const int ci = map_conv[ip];
+  for (int jp = blockIdx.x * blockDim.x + threadIdx.x; jp < n_new; jp += gridDim.x * blockDim.x) {
+    const int sj = map_src[jp];
+    const int cj = map_conv[jp];
+    T acc;
+    if (ci < 0 && cj < 0) {
+      acc = src[(size_t)si * ld + sj];
+    } else if (ci < 0) {
+      acc = T(0);
+      for (int b = 0; b < 6; ++b) acc += src[(size_t)si * ld + sj + b] * Jy[cj * 6 + b];
+    } else if (cj < 0) {
+      acc = T(0);
+      for (int a = 0; a < 6; ++a) acc += Jy[ci * 6 + a] * src[(size_t)(si + a) * ld + sj];
+    } else {
+      acc = T(0);
+      for (int a = 0; a < 6; ++a) {
+        T inner = T(0);
+        for (int b = 0; b < 6; ++b) inner += src[(size_t)(si + a) * ld + sj + b] * Jy[cj * 6 + b];
+        acc += Jy[ci * 6 + a] * inner;
+      }
+    }
+    dst[(size_t)ip * ld + jp] = acc;
+  }
+}
+
+// mu side of the same pass: pass-through copies or y = a + m / rho.
+template <typename T>
+__global__ void k_compact_mu(const T* __restrict__ src, T* __restrict__ dst, int n_new,
+                             const int* __restrict__ map_src, const int* __restrict__ map_conv,
+                             const T* __restrict__ Yxyz) {
+  const int ip = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ip >= n_new) return;
+  const int ci = map_conv[ip];
+  dst[ip] = (ci < 0) ? src[map_src[ip]] : Yxyz[ci];
+}
+
+// a14 linearity test per inverse-depth feature (vR.cpp:713-721) + the 3x6 Jacobian and the
+// XYZ point of every feature that passes.  out_flag[i] = 1 -> convert.
+template <typename T>
+__global__ void k_linearity(const T* __restrict__ mu, const T* __restrict__ S, int ld,
+                            const int* __restrict__ pos, const int* __restrict__ coding, int N,
+                            unsigned char* __restrict__ out_flag, T* __restrict__ Jy, T* __restrict__ Yxyz,
+                            int force_jacobian) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  if (coding[i] != 0) { out_flag[i] = 0; return; }
+  const int p = pos[i];
+  const T theta = mu[p + 3], phi = mu[p + 4], ro = mu[p + 5];
+  const T st = t_sin(theta), ct = t_cos(theta), sp = t_sin(phi), cp = t_cos(phi);
+  const T m[3] = {st * cp, -sp, ct * cp};
+  T y[3], d[3];
+  for (int k = 0; k < 3; ++k) { y[k] = mu[p + k] + m[k] / ro; d[k] = y[k] - mu[k]; }
+  const T sigma_rho = S[(size_t)(p + 5) * ld + p + 5];            // variance, vR.cpp:717
+  const T tt = d[0] * m[0] + d[1] * m[1] + d[2] * m[2];
+  const T Ld = T(4) * sigma_rho * t_abs(tt) / (ro * ro * (d[0] * d[0] + d[1] * d[1] + d[2] * d[2]));
+  const bool conv = force_jacobian || (Ld < T(0.01));
+  out_flag[i] = conv ? 1 : 0;
+  T* J = Jy + (size_t)i * 18;
+  for (int k = 0; k < 18; ++k) J[k] = T(0);
+  J[0] = T(1); J[7] = T(1); J[14] = T(1);
+  J[3] = ct * cp / ro;   J[9] = T(0);      J[15] = -st * cp / ro;
+  J[4] = -st * sp / ro;  J[10] = -cp / ro; J[16] = -ct * sp / ro;
+  J[5] = -m[0] / (ro * ro); J[11] = -m[1] / (ro * ro); J[17] = -m[2] / (ro * ro);
+  for (int k = 0; k < 3; ++k) Yxyz[(size_t)i * 3 + k] = y[k];
+}
+
+// f3: world point + 3x3 covariance of one feature (map export).
+template <typename T>
+__global__ void k_feature_xyz(const T* __restrict__ mu, const T* __restrict__ S, int ld,
+                              int p, int is_xyz, T* __restrict__ out /*3 + 9*/) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (is_xyz) {
+    for (int k = 0; k < 3; ++k) out[k] = mu[p + k];
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) out[3 + a * 3 + b] = S[(size_t)(p + a) * ld + p + b];
+    return;
+  }
+  const T theta = mu[p + 3], phi = mu[p + 4], ro = mu[p + 5];
+  const T st = t_sin(theta), ct = t_cos(theta), sp = t_sin(phi), cp = t_cos(phi);
+  const T m[3] = {st * cp, -sp, ct * cp};
+  T J[18];
+  for (int k = 0; k < 18; ++k) J[k] = T(0);
+  J[0] = T(1); J[7] = T(1); J[14] = T(1);
+  J[3] = ct * cp / ro;   J[9] = T(0);      J[15] = -st * cp / ro;
+  J[4] = -st * sp / ro;  J[10] = -cp / ro; J[16] = -ct * sp / ro;
+  J[5] = -m[0] / (ro * ro); J[11] = -m[1] / (ro * ro); J[17] = -m[2] / (ro * ro);
+  for (int k = 0; k < 3; ++k) out[k] = mu[p + k] + m[k] / ro;
+  T JS[18];
+  for (int a = 0; a < 3; ++a)
+    for (int c = 0; c < 6; ++c) {
+      T acc = T(0);
+      for (int k = 0; k < 6; ++k) acc += J[a * 6 + k] * S[(size_t)(p + k) * ld + p + c];
+      JS[a * 6 + c] = acc;
+    }
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) {
+      T acc = T(0);
+      for (int k = 0; k < 6; ++k) acc += JS[a * 6 + k] * J[b * 6 + k];
+      out[3 + a * 3 + b] = acc;
+    }
+}
+
+template <typename T>
+__global__ void k_fill(T* __restrict__ p, size_t count, T v) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+
+}  // namespace ekf

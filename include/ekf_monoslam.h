@@ -1,0 +1,181 @@
+/* ekf_monoslam.h -- C ABI of the MI355X-native EKF-MonoSLAM predict/update core.
+ *
+ * Drop-in boundary for the math methods of the reference's `class VSlamFilter`
+ * (mono-slam/src/vslamRansac.hpp:94-141 of engyasin/EKF-MonoSLAM_for_3D-reconstruction).
+ * The reference has no FFI today (it is a plain C++ class subclassed by RosVSLAM,
+ * RosVSLAMRansac.hpp:19-38); every entry point below names the reference method or
+ * source range it replaces.  "vR.cpp" = mono-slam/src/vslamRansac.cpp.
+ *
+ * Conventions
+ *  - every function returns an `int` status (EKF_OK = 0) unless it documents a count;
+ *    `ekf_last_error` gives the message of the last failure on that handle.
+ *  - the filter owns all device memory; every pointer crossing the ABI is a caller-owned
+ *    HOST buffer unless the parameter is named `d_*` (device pointer, resident in HBM).
+ *  - scalars are `float` for an EKF_F32 filter and `double` for an EKF_F64 filter;
+ *    such buffers are declared `void*`.
+ *  - matrices crossing the ABI are COLUMN-MAJOR (Eigen's default, so a
+ *    `VSlamFilter`-shaped C++ wrapper can `Eigen::Map` them directly).
+ *  - state layout (vR.hpp:12-25, vR.cpp:163-164, 483-486):
+ *      mu = [ r(0:3) | q=(w,x,y,z)(3:7) | v(7:10) | omega(10:13) | map_scale(13) | features... ]
+ *    inverse-depth feature = [x y z theta phi rho] (6), XYZ feature = [X Y Z] (3),
+ *    contiguous in insertion order.  camera_dim = 14 reproduces the reference
+ *    (#define STATE_DIM 14, vR.cpp:22); 13 drops the map-scale element.
+ *  - a handle is not thread-safe (the reference filter is single-threaded, node.cpp:865).
+ *  - there is no CPU fallback: without a HIP device `ekf_create` fails.
+ */
+#ifndef EKF_MONOSLAM_H_
+#define EKF_MONOSLAM_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EKF_ABI_VERSION 1
+
+typedef struct ekf_filter ekf_filter;
+
+enum ekf_dtype { EKF_F32 = 0, EKF_F64 = 1 };
+
+enum ekf_status {
+  EKF_OK = 0,
+  EKF_ERR_ARG = 1,         /* bad argument                                   */
+  EKF_ERR_CAPACITY = 2,    /* capacity_features exceeded                     */
+  EKF_ERR_DEVICE = 3,      /* HIP runtime failure                            */
+  EKF_ERR_STATE = 4,       /* call order (e.g. update before predict)        */
+  EKF_ERR_NUMERIC = 5,     /* innovation covariance not positive definite    */
+  EKF_ERR_UNSUPPORTED = 6
+};
+
+/* ConfigVSLAM (ConfigVSLAM.h:23-48) + camConfig (camModel.hpp:9-11) + frame size.
+ * fx, fy, u0, v0 are the values AFTER the reference's division by `scale`
+ * (ConfigVSLAM.cpp:87-103); image_width/height are frame.size() after the resize
+ * of captureNewFrame (vR.cpp:236). */
+typedef struct ekf_config {
+  float sigma_vx, sigma_vy, sigma_vz;
+  float sigma_wx, sigma_wy, sigma_wz;
+  float rho_0, sigma_rho_0;
+  int window_size, sigma_pixel, kernel_size, sigma_size, scale;
+  float T_camera;
+  int nInitFeatures, min_features, max_features, forsePlane;
+  float fx, fy, u0, v0, k1, k2, k3, p1, p2;
+  int image_width, image_height;
+} ekf_config;
+
+enum ekf_option {
+  /* 0: in-place strip kernel (touches 26 n elements); 1: streaming out-of-place
+   * Sigma' = F Sigma F^T + Q (reads n^2, writes n^2 -- the formulation the reference's
+   * `.eval()` at vR.cpp:477 has, and the one the HBM roofline of P-propagate is quoted on). */
+  EKF_OPT_PROPAGATE_STREAMING = 0,
+  /* 1 (default): hand-written MFMA kernels for the dense contractions; 0: plain VALU tiles. */
+  EKF_OPT_USE_MFMA = 1,
+  /* profiling level: 0 off, 1 HIP events around the dominant kernels, 2 around every kernel. */
+  EKF_OPT_PROFILE = 2
+};
+
+/* Fills `cfg` with the reference defaults (ConfigVSLAM.cpp:27-47, camModel.hpp:22-31). */
+void ekf_config_default(ekf_config* cfg);
+
+int ekf_abi_version(void);
+
+/* VSlamFilter::VSlamFilter (vR.cpp:142-223): mu0, Sigma0, Vmax, Vmax_n.  `device` is the HIP
+ * device ordinal.  capacity_features bounds numOfFeatures() for the life of the handle. */
+int ekf_create(const ekf_config* cfg, int camera_dim, int capacity_features, int dtype,
+               int device, ekf_filter** out);
+void ekf_destroy(ekf_filter* f);
+/* Message of the last failure (f may be NULL: last failure of ekf_create). */
+const char* ekf_last_error(const ekf_filter* f);
+
+/* captureNewFrame's dT (vR.cpp:226-233) and getDt (vR.cpp:247). */
+int ekf_set_dt(ekf_filter* f, double dT);
+double ekf_get_dt(const ekf_filter* f);
+
+/* Launch on a caller-provided hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
+int ekf_set_stream(ekf_filter* f, void* hip_stream);
+int ekf_set_option(ekf_filter* f, int option, int value);
+int ekf_synchronize(ekf_filter* f);
+
+/* VSlamFilter::addFeature (vR.cpp:309-371).  Returns 1 = added, 0 = pixel outside the image
+ * margin (vR.cpp:314), negative = -ekf_status. */
+int ekf_add_feature(ekf_filter* f, double u, double v);
+/* VSlamFilter::removeFeature (vR.cpp:373-421): splices the feature out of mu / Sigma and
+ * shifts position_in_state of later features. */
+int ekf_remove_feature(ekf_filter* f, int index);
+/* Batched removal, one compaction pass; same result as removing the listed indices in
+ * descending order (the order of the loop at vR.cpp:1296-1299). */
+int ekf_remove_features(ekf_filter* f, const int* indices, int count);
+
+/* VSlamFilter::predict (vR.cpp:451-603) without the image blur: covariance propagation
+ * Sigma <- F Sigma F^T + Q, Predict_State, and for every feature h, the compact
+ * measurement Jacobian (2x7 camera block + 2x6 / 2x3 feature block), the visibility test
+ * (vR.cpp:529) and the rho <= 0 removal flag (vR.cpp:517-521), and the 2x2 diagonal block
+ * of St = H Sigma H^T + sigma_px^2 I that `Patch::findMatch` is gated with (vR.cpp:875).
+ * t_ctl / r_ctl: 3 scalars each (may be NULL = 0); vcontrol selects Vmax vs Vmax_n. */
+int ekf_predict(ekf_filter* f, const void* t_ctl, const void* r_ctl, int vcontrol);
+/* Re-evaluates h / H / flags / 2x2 blocks at the current state (the recomputation at
+ * vR.cpp:1080-1117 before the high-innovation update). */
+int ekf_measure(ekf_filter* f);
+
+/* Per-feature outputs of the last predict/measure.  Any pointer may be NULL.
+ * h: 2 per feature; visible / remove_flag: 1 byte per feature; S2x2: 4 per feature,
+ * column-major 2x2; Hc: 14 per feature (2x7 column-major); Hf: 12 per feature (2x6
+ * column-major, last 3 columns zero for an XYZ feature). */
+int ekf_get_predictions(ekf_filter* f, void* h, unsigned char* visible,
+                        unsigned char* remove_flag, void* S2x2, void* Hc, void* Hf);
+
+/* The EKF update block (vR.cpp:1245-1284; the same block at 1053-1061 and 663-676):
+ * St = H Sigma H^T + R, Kt = Sigma H^T St^-1, mu += Kt (z - h), Sigma <- (I - Kt H) Sigma,
+ * normalizeQuaternion (vR.cpp:1625-1642).  `indices` (ascending feature indices, M of them)
+ * is the measured set, z holds 2 pixels per listed feature.  plane_constraint != 0 appends
+ * the forsePlane pseudo-measurement (vR.cpp:1250-1263, 1272).  M = 0 and no plane: no-op. */
+int ekf_update(ekf_filter* f, const void* z, const int* indices, int M, int plane_constraint);
+/* Same with z / indices already resident in device memory. */
+int ekf_update_device(ekf_filter* f, const void* d_z, const int* d_indices, int M,
+                      int plane_constraint);
+
+/* Full St for a measured set (vR.cpp:598): out is m x m column-major, m = 2M (+3). */
+int ekf_innovation_covariance(ekf_filter* f, const int* indices, int M, int plane_constraint,
+                              void* S_out);
+/* Kt of the last update (n x m column-major, n = state dim before normalisation). */
+int ekf_get_gain(ekf_filter* f, void* K_out);
+int ekf_last_measurement_rows(const ekf_filter* f);
+
+/* VSlamFilter::convert2XYZ_ifLinear (vR.cpp:741-772): returns 1 converted, 0 not, <0 error. */
+int ekf_convert_xyz_if_linear(ekf_filter* f, int index);
+/* VSlamFilter::convert2XYZ_ifLinearAll (vR.cpp:776-780): returns the number converted. */
+int ekf_convert_xyz_if_linear_all(ekf_filter* f);
+
+/* numOfFeatures (vR.cpp:127-129) and mu.size(). */
+int ekf_num_features(const ekf_filter* f);
+int ekf_state_dim(const ekf_filter* f);
+/* Patch::position_in_state / Patch::coding (0 = inverse depth, 1 = XYZ) per feature. */
+int ekf_get_feature_layout(const ekf_filter* f, int* position_in_state, int* coding);
+
+/* getState (vR.cpp:135-140) generalised to any segment; set_* inject test inputs. */
+int ekf_get_state(ekf_filter* f, void* out, int offset, int count);
+int ekf_set_state(ekf_filter* f, const void* in, int offset, int count);
+/* getSigma (vR.cpp:131-133) generalised to any block (RosVSLAM reads Sigma.block directly,
+ * RosVSLAMRansac.cpp:171-183). Column-major rows x cols. */
+int ekf_get_sigma_block(ekf_filter* f, void* out, int r0, int c0, int rows, int cols);
+int ekf_set_sigma_block(ekf_filter* f, const void* in, int r0, int c0, int rows, int cols);
+/* Covariance_Parameter (vR.cpp:841-866): trace of Sigma[0:7,0:7]. */
+int ekf_covariance_parameter(ekf_filter* f, double* out);
+/* inverseDepth2XyzWorld mode 1 + Jf Sigma_ff Jf^T (vR.cpp:690-738,
+ * RosVSLAMRansac.cpp:177-183): world point (3) and 3x3 covariance (column-major). */
+int ekf_feature_xyz(ekf_filter* f, int index, void* xyz, void* cov3x3);
+
+/* Per-kernel HIP-event timing (EKF_OPT_PROFILE).  Kernel ids are dense in
+ * [0, ekf_profile_kernels()). */
+int ekf_profile_kernels(void);
+const char* ekf_profile_kernel_name(int kernel_id);
+int ekf_profile_read(ekf_filter* f, int kernel_id, double* total_ms, long long* launches);
+int ekf_profile_reset(ekf_filter* f);
+
+/* Raw device pointers for zero-copy plumbing (torch / RCCL): mu, the live Sigma buffer,
+ * and its leading dimension (device storage is row-major, ld elements per row). */
+void* ekf_device_mu(ekf_filter* f);
+void* ekf_device_sigma(ekf_filter* f, int* ld);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EKF_MONOSLAM_H_ */

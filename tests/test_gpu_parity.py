@@ -1,0 +1,205 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle on identical inputs.
+Tolerances are rel-Frobenius, calibrated against the oracle's own fp32-vs-fp64 gap
+(tests/test_oracle_flavours.py): fp64 HIP vs fp64 oracle <= 1e-10 on Sigma, fp32 <= 2e-4."""
+import numpy as np
+import pytest
+
+import ekf_oracle as o
+from helpers import gpu_state, make_pair, relf
+
+pytestmark = pytest.mark.gpu
+
+TOL = {np.float64: dict(mu=1e-12, S=1e-10, h=1e-10, H=1e-10),
+       np.float32: dict(mu=2e-5, S=2e-4, h=2e-3, H=2e-4)}
+
+
+def step(ref, g, seed=1235, plane=False):
+    ref.predict()
+    g.predict()
+    vis = ref.visible_indices()
+    z = o.synthetic_measurements(ref, vis, seed=seed)
+    ref.update(z, vis, plane=plane)
+    g.update(z, vis, plane_constraint=plane)
+    return vis, z
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_add_feature_matches_oracle(dtype):
+    ref, g = make_pair(20, dtype, inject=False)
+    mu, S = gpu_state(g)
+    assert g.stateDim() == ref.n == 14 + 6 * 20
+    pos, cod = g.featureLayout()
+    assert list(pos) == [ft.position_in_state for ft in ref.features] and not cod.any()
+    t = TOL[dtype]
+    assert relf(mu, ref.mu) < t["mu"] * 10
+    assert relf(S, ref.Sigma) < t["S"]
+    assert g.addFeature((3.0, 100.0)) == 0            # outside the margin, vR.cpp:314
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("streaming", [0, 1])
+def test_predict_matches_oracle(dtype, streaming):
+    ref, g = make_pair(20, dtype)
+    g.set_option(0, streaming)
+    ref.predict([0.01, 0.0, -0.02], [0.0, 0.01, 0.0], True)
+    g.predict([0.01, 0.0, -0.02], [0.0, 0.01, 0.0], True)
+    mu, S = gpu_state(g)
+    t = TOL[dtype]
+    assert relf(mu, ref.mu) < t["mu"]
+    assert relf(S, ref.Sigma) < t["S"]
+    h, vis, rem, S2, Hc, Hf = g.predictions(jacobians=True)
+    assert list(np.nonzero(vis)[0]) == ref.visible_indices()
+    assert not rem.any()
+    for i, ft in enumerate(ref.features):
+        assert np.allclose(h[i], ft.h, atol=t["h"])
+        assert relf(Hc[i], ft.Hc) < t["H"]
+        assert relf(Hf[i], ft.Hf) < t["H"]
+        k = ft.position_in_z
+        assert relf(S2[i], ref.St[k:k + 2, k:k + 2]) < t["S"] * 5
+    # second predict exercises the buffer flip of the streaming mode
+    ref.predict()
+    g.predict()
+    mu, S = gpu_state(g)
+    assert relf(S, ref.Sigma) < t["S"]
+
+
+@pytest.mark.parametrize("dtype,mfma", [(np.float64, False), (np.float32, False), (np.float32, True)])
+@pytest.mark.parametrize("n_feat", [20, 50])
+def test_update_matches_oracle(dtype, mfma, n_feat):
+    ref, g = make_pair(n_feat, dtype, mfma=mfma)
+    vis, z = step(ref, g)
+    g.synchronize()
+    mu, S = gpu_state(g)
+    t = TOL[dtype]
+    assert relf(mu, ref.mu) < t["mu"] * 5
+    assert relf(S, ref.Sigma) < t["S"]
+    K = g.getGain()
+    assert K.shape == ref.Kt.shape
+    assert relf(K, ref.Kt) < t["S"] * 20
+    assert abs(np.linalg.norm(mu[3:7]) - 1.0) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_innovation_covariance_matches_oracle(dtype):
+    ref, g = make_pair(20, dtype)
+    ref.predict()
+    g.predict()
+    vis = ref.visible_indices()
+    St = g.innovationCovariance(vis)
+    assert relf(St, ref.St) < TOL[dtype]["S"]
+    sub = vis[3:11]
+    assert relf(g.innovationCovariance(sub), ref.innovation_covariance(sub)) < TOL[dtype]["S"]
+    assert relf(g.innovationCovariance(sub, True), ref.innovation_covariance(sub, True)) < TOL[dtype]["S"]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_dense_reference_formulation_agrees(dtype):
+    """The faithful-dense oracle (the reference's own n^3 products) against the HIP path."""
+    ref, g = make_pair(20, dtype, flavour=o.DenseFilter)
+    step(ref, g)
+    step(ref, g, seed=1236)
+    mu, S = gpu_state(g)
+    assert relf(mu, ref.mu) < TOL[dtype]["mu"] * 10
+    assert relf(S, ref.Sigma) < TOL[dtype]["S"] * 2
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_subset_and_plane_update(dtype):
+    ref, g = make_pair(24, dtype)
+    ref.predict()
+    g.predict()
+    vis = ref.visible_indices()[::2]
+    z = o.synthetic_measurements(ref, vis)
+    ref.update(z, vis, plane=True)
+    g.update(z, vis, plane_constraint=True)
+    mu, S = gpu_state(g)
+    assert relf(mu, ref.mu) < TOL[dtype]["mu"] * 5
+    assert relf(S, ref.Sigma) < TOL[dtype]["S"]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_remove_and_convert(dtype):
+    ref, g = make_pair(12, dtype)
+    step(ref, g)
+    # force two features through the linearity test on both sides
+    for i in (2, 7):
+        p = ref.features[i].position_in_state
+        ref.Sigma[p + 5, p + 5] = 1e-9
+    g.setFullState(ref.mu)
+    g.setSigmaBlock(ref.Sigma)
+    assert ref.convert2xyz_if_linear_all() == 2
+    assert g.convert2XYZ_ifLinearAll() == 2
+    pos, cod = g.featureLayout()
+    assert list(pos) == [ft.position_in_state for ft in ref.features]
+    assert list(cod) == [ft.coding for ft in ref.features]
+    mu, S = gpu_state(g)
+    t = TOL[dtype]
+    assert relf(mu, ref.mu) < t["mu"] * 5 and relf(S, ref.Sigma) < t["S"]
+    for i in (9, 4, 0):                              # descending, like vR.cpp:1296-1299
+        ref.remove_feature(i)
+    g.removeFeatures([0, 4, 9])
+    assert g.numOfFeatures() == 9 and g.stateDim() == ref.n
+    mu, S = gpu_state(g)
+    assert relf(mu, ref.mu) < t["mu"] * 5 and relf(S, ref.Sigma) < t["S"]
+    xyz, cov = g.featureXYZ(1)                        # an XYZ feature after the shifts
+    y_ref, c_ref = ref.feature_xyz(1)
+    assert relf(xyz, y_ref) < t["mu"] * 10 and relf(cov, c_ref) < t["S"] * 10
+    xyz, cov = g.featureXYZ(0)                        # inverse-depth feature: Jf Sigma Jf^T
+    y_ref, c_ref = ref.feature_xyz(0)
+    assert relf(xyz, y_ref) < t["mu"] * 100 and relf(cov, c_ref) < t["S"] * 100
+    # mixed XYZ / inverse-depth map keeps working, and a new feature lands at the end
+    assert g.addFeature((100.0, 90.0)) == 1 and ref.add_feature(100.0, 90.0) == 1
+    g.setFullState(ref.mu)
+    g.setSigmaBlock(ref.Sigma)
+    step(ref, g, seed=99)
+    mu, S = gpu_state(g)
+    assert relf(mu, ref.mu) < t["mu"] * 10 and relf(S, ref.Sigma) < t["S"] * 2
+
+
+def test_getters_match_reference_semantics():
+    ref, g = make_pair(8, np.float32)
+    step(ref, g)
+    assert g.getState().shape == (14,) and g.getSigma().shape == (14, 14)
+    assert np.isclose(g.Covariance_Parameter(), float(ref.covariance_parameter()), rtol=1e-3)
+    assert g.numOfFeatures() == 8 and np.isclose(g.getDt(), 1.0 / 30.0)
+    blk = g.getSigmaBlock(14, 0, 6, 7)
+    assert relf(blk, ref.Sigma[14:20, 0:7]) < 1e-3
+
+
+def test_camera_dim_13():
+    ref, g = make_pair(10, np.float64, camera_dim=13)
+    step(ref, g)
+    mu, S = gpu_state(g)
+    assert g.stateDim() == 13 + 60
+    assert relf(S, ref.Sigma) < 1e-10
+
+
+def test_n200_stream_tracks_oracle():
+    """configs[1] shape (N=200, fp32): per-frame comparison with re-sync every 5 frames."""
+    ref, g = make_pair(200, np.float32)
+    worst = 0.0
+    for k in range(10):
+        step(ref, g, seed=2000 + k)
+        mu, S = gpu_state(g)
+        worst = max(worst, relf(S, ref.Sigma))
+        assert relf(mu, ref.mu) < 5e-4
+        if k % 5 == 4:
+            g.setFullState(ref.mu)
+            g.setSigmaBlock(ref.Sigma)
+    assert worst < 2e-3
+
+
+def test_error_paths():
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    ref, g = make_pair(4, np.float32, capacity=4)
+    with pytest.raises(pkg.EkfError):                 # capacity
+        g.addFeature((100.0, 100.0))
+    with pytest.raises(pkg.EkfError):                 # update before predict
+        g.update(np.zeros(2, np.float32), [0])
+    g.predict()
+    with pytest.raises(pkg.EkfError):
+        g.update(np.zeros(2, np.float32), [7])
+    with pytest.raises(pkg.EkfError):
+        g.removeFeature(11)
+    g.update()                                        # M = 0, no plane: no-op (vR.cpp:1266)
