@@ -244,7 +244,7 @@ class CamModel:
     def __init__(self, cfg: Config, T):
         self.T = T
         for k in ("fx", "fy", "u0", "v0", "k1", "k2", "k3", "p1", "p2"):
-            setattr(self, k, T(getattr(cfg, k)))
+            setattr(self, k, T(np.float32(getattr(cfg, k))))   # camConfig fields are float
 
     def diff_distort(self, hn):
         """diff_distort_undistort, cam.cpp:18-47: D(hn), 2x2."""
@@ -388,7 +388,7 @@ class DenseFilter:
         # vR.cpp:194-202
         Vmax = np.eye(6, dtype=T)
         for i, k in enumerate(("sigma_vx", "sigma_vy", "sigma_vz", "sigma_wx", "sigma_wy", "sigma_wz")):
-            s = T(getattr(cfg, k))
+            s = T(np.float32(getattr(cfg, k)))                 # ConfigVSLAM fields are float
             Vmax[i, i] = s * s
         self.Vmax = Vmax
         self.Vmax_n = Vmax * T(2)
@@ -441,7 +441,7 @@ class DenseFilter:
         hx, hy, hz = hW
         theta = T(np.arctan2(hx, hz))
         phi = T(np.arctan2(-hy, np.sqrt(hx*hx + hz*hz)))
-        f = np.array([r[0], r[1], r[2], theta, phi, T(cfg.rho_0)], dtype=T)
+        f = np.array([r[0], r[1], r[2], theta, phi, T(np.float32(cfg.rho_0))], dtype=T)
         J_f_hW = jacobian_inv_feature_to_hW(hW, T)
         J_hW_q = jacobian_rq_d(q, hC, T)
         G = np.zeros((6, 7), dtype=T)
@@ -466,7 +466,7 @@ class DenseFilter:
         Js[nOld+5, nOld+2] = 1
         S = T(self.sigma_pixel_2) * np.eye(nOld + 3, dtype=T)
         S[:nOld, :nOld] = self.Sigma
-        S[nOld+2, nOld+2] = T(self.cfg.sigma_rho_0)     # unsquared, vR.cpp:365
+        S[nOld+2, nOld+2] = T(np.float32(self.cfg.sigma_rho_0))     # unsquared, vR.cpp:365
         self.Sigma = Js @ S @ Js.T                       # vR.cpp:367
         return 1
 
@@ -742,7 +742,7 @@ class StructuredFilter(DenseFilter):
         S[n:, :n] = B
         S[:n, n:] = (self.Sigma[:, 0:7] @ G.T)
         C = G @ self.Sigma[0:7, 0:7] @ G.T + T(self.sigma_pixel_2) * (Jp @ Jp.T)
-        C[5, 5] += T(self.cfg.sigma_rho_0)
+        C[5, 5] += T(np.float32(self.cfg.sigma_rho_0))
         S[n:, n:] = C
         self.Sigma = S
         return 1
