@@ -269,14 +269,10 @@ __global__ void k_measure(const T* __restrict__ mu, const T* __restrict__ S, int
   unsigned char fl = 0;
   if (!xyz) {
     const T theta = f[3], phi = f[4], ro = f[5];
-    if (ro <= T(0)) {
-      flags[i] = 2;
-      h_out[2 * i] = T(0); h_out[2 * i + 1] = T(0);
-      for (int k = 0; k < 14; ++k) Hc[(size_t)i * 14 + k] = T(0);
-      for (int k = 0; k < 12; ++k) Hf[(size_t)i * 12 + k] = T(0);
-      for (int k = 0; k < 4; ++k) Sd[(size_t)i * 4 + k] = T(0);
-      return;
-    }
+    // rho <= 0: flagged for removal and never "visible" (vR.cpp:517-522).  h / H are still
+    // evaluated (the formulas are regular there) so a caller that forces the feature into an
+    // update list gets a consistent linearisation instead of stale values.
+    if (ro <= T(0)) fl |= 2;
     const T st = t_sin(theta), ct = t_cos(theta), sp = t_sin(phi), cp = t_cos(phi);
     const T m[3] = {st * cp, -sp, ct * cp};
     const T ar[3] = {f[0] - r[0], f[1] - r[1], f[2] - r[2]};
@@ -297,7 +293,7 @@ __global__ void k_measure(const T* __restrict__ mu, const T* __restrict__ S, int
   mat3_vec(R, d, hC);
   T hd[2], Jp[6];
   project_distort(cam, hC, hd, Jp);
-  if (inside_image(cam, hd[0], hd[1]) && hC[2] >= T(0)) fl |= 1;
+  if (!(fl & 2) && inside_image(cam, hd[0], hd[1]) && hC[2] >= T(0)) fl |= 1;
   // JR = Jp * R (2x3)
   T JR[6];
   for (int a = 0; a < 2; ++a)

@@ -524,8 +524,7 @@ class DenseFilter:
         pos = ft.position_in_state
         if ft.coding == INV:
             f = mu[pos:pos+6]
-            if f[5] <= 0:                                               # vR.cpp:517-522
-                return None, None, None, False, True
+            rem = bool(f[5] <= 0)                                       # vR.cpp:517-522
             d, J_hW_f = inverse2xyz_projecting(f, r, T, True)
             scale_r = -f[5]
         else:
@@ -533,27 +532,27 @@ class DenseFilter:
             d = y - r
             J_hW_f = np.eye(3, dtype=T)
             scale_r = T(-1)
+            rem = False
         hC = RotCW @ d
         hi, J_h_hC = self.cam.project(hC, True)
-        vis = is_inside_image(hi, cfg.image_width, cfg.image_height, cfg.window_size) and bool(hC[2] >= 0)
+        vis = (not rem) and is_inside_image(hi, cfg.image_width, cfg.image_height, cfg.window_size) \
+            and bool(hC[2] >= 0)
         J_hC_q = jacobian_rq_d(qc, d, T) @ d_qbar_q(T)                   # vR.cpp:537
         Hc = np.zeros((2, 7), dtype=T)
         Hc[:, 0:3] = scale_r * (J_h_hC @ RotCW)                          # vR.cpp:539 / 568
         Hc[:, 3:7] = J_h_hC @ J_hC_q                                     # vR.cpp:540
         Hf = J_h_hC @ RotCW @ J_hW_f                                     # vR.cpp:541 / 570
-        return hi, Hc, Hf, vis, False
+        return hi, Hc, Hf, vis, rem
 
     def measure(self):
         for ft in self.features:
             hi, Hc, Hf, vis, rem = self.measure_feature(ft)
             if rem:
                 ft.remove_flag = True
-                ft.is_in_innovation = False
-                continue
             ft.is_in_innovation = vis
-            # the reference `continue`s before storing h/H of an invisible
-            # feature (vR.cpp:533); the values are kept here so a caller may
-            # still force such a feature into an update list.
+            # the reference `continue`s before storing h/H of an invisible or
+            # rho <= 0 feature (vR.cpp:521, 533); the values are kept here so a
+            # caller may still force such a feature into an update list.
             ft.h, ft.Hc, ft.Hf = hi, Hc, Hf
         j = 0
         for ft in self.features:                                        # vR.cpp:584-592

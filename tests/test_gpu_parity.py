@@ -203,3 +203,17 @@ def test_error_paths():
     with pytest.raises(pkg.EkfError):
         g.removeFeature(11)
     g.update()                                        # M = 0, no plane: no-op (vR.cpp:1266)
+
+
+def test_nonpositive_rho_is_flagged_not_visible():     # vR.cpp:517-522
+    ref, g = make_pair(6, np.float32)
+    mu = ref.mu.copy()
+    mu[ref.features[2].position_in_state + 5] = -0.05
+    ref.mu = mu
+    g.setFullState(mu)
+    ref.measure()
+    g.measure()
+    h, vis, rem, S2, Hc, Hf = g.predictions(jacobians=True)
+    assert rem[2] and not vis[2] and rem.sum() == 1
+    assert ref.features[2].remove_flag and not ref.features[2].is_in_innovation
+    assert relf(Hf[2], ref.features[2].Hf) < 1e-3 and np.allclose(h[2], ref.features[2].h, atol=1e-2)
