@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-propagate-pass", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--pipeline", type=int, default=1, help="EKF_OPT_PIPELINE (overlap chain with solve/downdate pieces)")
     return ap.parse_args()
 
 
@@ -124,6 +125,7 @@ def main():
 
 def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
     flt = build_filter(pkg, cfg, n_feat, px0)
+    flt.set_option(3, args.pipeline)
     n = flt.stateDim()
     d_z = torch.from_numpy(z.reshape(z.shape[0], -1)).to(dev).contiguous()
     d_idx = torch.arange(n_feat, dtype=torch.int32, device=dev)

@@ -30,6 +30,7 @@ enum KernelId : int {
   KID_CHOL_TRAILING,
   KID_STATE_UPDATE,
   KID_DOWNDATE,
+  KID_SOLVE,
   KID_NORMALIZE,
   KID_ADD_FEATURE,
   KID_COMPACT,
@@ -41,7 +42,7 @@ static const char* kKernelNames[KID_COUNT] = {
     "predict_camera",  "propagate_strips", "propagate_streaming", "measure",
     "innovation",      "sigma_ht",         "innovation_cov",      "chol_diag",
     "chol_panel",      "chol_trailing",    "state_update",        "downdate_syrk",
-    "normalize_quat",  "add_feature",      "compact_transform",   "misc"};
+    "solve_trmm",      "normalize_quat",  "add_feature",      "compact_transform",   "misc"};
 
 static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
@@ -121,8 +122,10 @@ struct Filter : FilterBase {
   T *d_Jy = nullptr, *d_Yxyz = nullptr;
   int *d_map_src = nullptr, *d_map_conv = nullptr;
   // update workspace
-  int m_cap = 0, ldy = 0, y_rows = 0;
-  T* d_Y = nullptr;
+  int m_cap = 0, ldy = 0, w_rows = 0;
+  T* d_Y = nullptr;                                     // [S; Z], 2 ldy rows
+  T* d_W = nullptr;                                     // [W; nu block], n_pad + 128 rows
+  T* d_V = nullptr;                                     // [V; y block]
   T* d_Dinv = nullptr;
   T* d_z = nullptr;
   int* d_midx = nullptr;
@@ -137,6 +140,14 @@ struct Filter : FilterBase {
   int opt_streaming = 0, opt_mfma = 1, opt_profile = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t stream_b = nullptr;                       // overlaps solve / downdate pieces with the chain
+  hipEvent_t ev_chain[8] = {}, ev_b = nullptr;
+  int opt_pipeline = 1;
+  int* d_tilemap = nullptr;                             // work lists: [lower-tri super-tiles | solve heavy-first]
+  int tilemap_nt = 0, tilemap_ntc = 0, tri_count = 0, solve_off = 0;
+  int* d_counters = nullptr;                            // one work-queue head per queued launch of an update
+  int counter_next = 0;
+  int num_cus = 256;
   // profiling
   struct Pending { int kid; hipEvent_t a, b; };
   std::vector<Pending> pending;
@@ -153,10 +164,13 @@ struct Filter : FilterBase {
     for (auto& p : pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : pool) hipEventDestroy(e);
     void* ptrs[] = {d_pos, d_coding, d_mu[0], d_mu[1], d_S[0], d_S[1], d_scr, d_h, d_Hc, d_Hf, d_Sd,
-                    d_flags, d_cflag, d_Jy, d_Yxyz, d_map_src, d_map_conv, d_Y, d_Dinv, d_z, d_midx,
-                    d_status, d_tmp, d_K};
+                    d_flags, d_cflag, d_Jy, d_Yxyz, d_map_src, d_map_conv, d_Y, d_W, d_V, d_Dinv, d_z, d_midx,
+                    d_status, d_tmp, d_K, d_tilemap, d_counters};
     for (void* p : ptrs) if (p) hipFree(p);
     if (own_stream && stream) hipStreamDestroy(stream);
+    if (stream_b) hipStreamDestroy(stream_b);
+    for (auto e : ev_chain) if (e) hipEventDestroy(e);
+    if (ev_b) hipEventDestroy(ev_b);
   }
 
   // ---- profiling helpers ---------------------------------------------------------------
@@ -164,7 +178,7 @@ struct Filter : FilterBase {
     if (opt_profile >= 2) return true;
     if (opt_profile == 1)
       return kid == KID_DOWNDATE || kid == KID_PROPAGATE_STREAMING || kid == KID_PROPAGATE_STRIPS ||
-             kid == KID_SIGMA_HT;
+             kid == KID_SIGMA_HT || kid == KID_SOLVE;
     return false;
   }
   hipEvent_t get_event() {
@@ -174,17 +188,19 @@ struct Filter : FilterBase {
     return e;
   }
   struct Scope {
-    Filter* f; int kid; hipEvent_t a = nullptr, b = nullptr; bool on;
-    Scope(Filter* f_, int kid_) : f(f_), kid(kid_), on(f_->prof_on(kid_)) {
-      if (on) { a = f->get_event(); b = f->get_event(); hipEventRecord(a, f->stream); }
+    Filter* f; int kid; hipEvent_t a = nullptr, b = nullptr; bool on; hipStream_t st;
+    Scope(Filter* f_, int kid_, hipStream_t st_ = nullptr)
+        : f(f_), kid(kid_), on(f_->prof_on(kid_)), st(st_ ? st_ : f_->stream) {
+      if (on) { a = f->get_event(); b = f->get_event(); hipEventRecord(a, st); }
     }
     ~Scope() {
-      if (on) { hipEventRecord(b, f->stream); f->pending.push_back({kid, a, b}); }
+      if (on) { hipEventRecord(b, st); f->pending.push_back({kid, a, b}); }
     }
   };
   void resolve_profile() {
     if (pending.empty()) return;
     hipStreamSynchronize(stream);
+    hipStreamSynchronize(stream_b);
     for (auto& p : pending) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { prof_ms[p.kid] += ms; prof_cnt[p.kid] += 1; }
@@ -204,7 +220,7 @@ struct Filter : FilterBase {
     ld = n_pad;
     m_cap = 2 * capN + 3;
     ldy = round_up(m_cap, 128);
-    y_rows = ldy + n_pad + 128;
+    w_rows = n_pad + 128;
     memset(prof_ms, 0, sizeof(prof_ms));
     memset(prof_cnt, 0, sizeof(prof_cnt));
     cam.fx = c->fx; cam.fy = c->fy; cam.u0 = c->u0; cam.v0 = c->v0;
@@ -214,8 +230,15 @@ struct Filter : FilterBase {
     const float sv[6] = {c->sigma_vx, c->sigma_vy, c->sigma_vz, c->sigma_wx, c->sigma_wy, c->sigma_wz};
     for (int i = 0; i < 6; ++i) vmax[i] = double(T(sv[i]) * T(sv[i]));  // vR.cpp:194-200
     HIPCHK(hipSetDevice(device));
-    HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    {
+      int lo = 0, hi = 0;
+      HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      HIPCHK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi));   // the serial chain goes first
+      HIPCHK(hipStreamCreateWithPriority(&stream_b, hipStreamNonBlocking, lo));
+    }
     own_stream = true;
+    for (auto& e : ev_chain) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ev_b, hipEventDisableTiming));
     const size_t sig = (size_t)n_pad * ld;
     HIPCHK(hipMalloc(&d_S[0], sig * sizeof(T)));
     HIPCHK(hipMalloc(&d_S[1], sig * sizeof(T)));
@@ -239,14 +262,24 @@ struct Filter : FilterBase {
     HIPCHK(hipMalloc(&d_Yxyz, cn * 3 * sizeof(T)));
     HIPCHK(hipMalloc(&d_map_src, (size_t)n_pad * sizeof(int)));
     HIPCHK(hipMalloc(&d_map_conv, (size_t)n_pad * sizeof(int)));
-    HIPCHK(hipMalloc(&d_Y, (size_t)y_rows * ldy * sizeof(T)));
-    HIPCHK(hipMemsetAsync(d_Y, 0, (size_t)y_rows * ldy * sizeof(T), stream));
+    HIPCHK(hipMalloc(&d_Y, (size_t)2 * ldy * ldy * sizeof(T)));
+    HIPCHK(hipMemsetAsync(d_Y, 0, (size_t)2 * ldy * ldy * sizeof(T), stream));
+    HIPCHK(hipMalloc(&d_W, (size_t)w_rows * ldy * sizeof(T)));
+    HIPCHK(hipMemsetAsync(d_W, 0, (size_t)w_rows * ldy * sizeof(T), stream));
+    HIPCHK(hipMalloc(&d_V, (size_t)w_rows * ldy * sizeof(T)));
+    HIPCHK(hipMemsetAsync(d_V, 0, (size_t)w_rows * ldy * sizeof(T), stream));
     HIPCHK(hipMalloc(&d_Dinv, (size_t)(ldy / 64) * 128 * 128 * sizeof(T)));
     HIPCHK(hipMalloc(&d_z, (size_t)ldy * sizeof(T)));
     HIPCHK(hipMalloc(&d_midx, cn * sizeof(int)));
     HIPCHK(hipMalloc(&d_status, 4 * sizeof(int)));
     HIPCHK(hipMemsetAsync(d_status, 0, 4 * sizeof(int), stream));
     HIPCHK(hipMalloc(&d_tmp, 64 * sizeof(T)));
+    HIPCHK(hipMalloc(&d_counters, 64 * sizeof(int)));
+    {
+      hipDeviceProp_t prop;
+      HIPCHK(hipGetDeviceProperties(&prop, device));
+      num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     // mu0 / Sigma0 (vR.cpp:163-180, 211-216)
     std::vector<T> mu0(camera_dim, T(0));
     mu0[3] = T(0.0); mu0[4] = T(0.0); mu0[5] = T(-0.707106781); mu0[6] = T(0.707106781);
@@ -315,6 +348,7 @@ struct Filter : FilterBase {
       case EKF_OPT_PROPAGATE_STREAMING: opt_streaming = v ? 1 : 0; return EKF_OK;
       case EKF_OPT_USE_MFMA: opt_mfma = v ? 1 : 0; return EKF_OK;
       case EKF_OPT_PROFILE: resolve_profile(); opt_profile = v; return EKF_OK;
+      case EKF_OPT_PIPELINE: opt_pipeline = v ? 1 : 0; return EKF_OK;
       default: FAIL(EKF_ERR_ARG, "unknown option");
     }
   }
@@ -519,18 +553,56 @@ struct Filter : FilterBase {
   }
 
   // ---- dense tile GEMM dispatch -----------------------------------------------------------
-  // C[rows x cols] = beta C + alpha A B^T ; rows, cols multiples of the tile.
+  // C[rows x cols] = beta C + alpha A op(B); rows, cols multiples of the tile.
+  template <int ROLE, bool BT>
   void gemm(const T* A, int lda, const T* B, int ldb, T* C, int ldc, int rows, int cols, int K, T alpha, T beta,
-            int tri, int row_off, int col_off) {
+            int tri, int row_off, int col_off, int ktri, int ktile_off = 0, hipStream_t st = nullptr,
+            const int* tile_list = nullptr, int ntiles = 0) {
+    GemmArgs g{A, lda, B, ldb, C, ldc, K, double(alpha), double(beta), tri, row_off, col_off, ktri, ktile_off,
+               nullptr, 0, nullptr};
+    if (!st) st = stream;
+    const int ts = (kIsF32 && opt_mfma) ? 128 : 64;
+    dim3 grid(cols / ts, rows / ts);
+    if (tile_list && counter_next < 64) {
+      g.tile_map = tile_list;
+      g.ntiles = ntiles;
+      g.counter = d_counters + counter_next++;
+      grid = dim3(std::min(ntiles, 2 * num_cus), 1);
+    }
     if constexpr (kIsF32) {
       if (opt_mfma) {
-        dim3 grid(cols / 128, rows / 128);
-        k_gemm_nt_mfma<<<grid, 256, 0, stream>>>(A, lda, B, ldb, C, ldc, K, alpha, beta, tri, row_off, col_off);
+        k_gemm_mfma<ROLE, BT><<<grid, 256, 0, st>>>(g);
         return;
       }
     }
-    dim3 grid(cols / 64, rows / 64);
-    k_gemm_nt_valu<T><<<grid, 256, 0, stream>>>(A, lda, B, ldb, C, ldc, K, alpha, beta, tri, row_off, col_off);
+    k_gemm_valu<T, ROLE, BT><<<grid, 256, 0, st>>>(g);
+  }
+
+  // Work lists for the queued GEMMs: (1) lower-triangular tiles of an nt x nt grid in 8x8
+  // super-tiles; (2) the ntr x ntc tiles of the triangular solve, heaviest (largest bj) first.
+  int ensure_tilemap(int nt, int ntr, int ntc) {
+    if (tilemap_nt == nt && tilemap_ntc == ntc) return EKF_OK;
+    std::vector<int> tm;
+    const int SB = 8;
+    const int ns = (nt + SB - 1) / SB;
+    for (int si = 0; si < ns; ++si)
+      for (int sj = 0; sj <= si; ++sj)
+        for (int i = si * SB; i < std::min(nt, (si + 1) * SB); ++i)
+          for (int j = sj * SB; j < std::min(nt, (sj + 1) * SB); ++j)
+            if (j <= i) { tm.push_back(i); tm.push_back(j); }
+    tri_count = (int)tm.size() / 2;
+    solve_off = (int)tm.size();
+    for (int j = ntc - 1; j >= 0; --j)
+      for (int i = 0; i < ntr; ++i) { tm.push_back(i); tm.push_back(j); }
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipStreamSynchronize(stream_b));
+    if (d_tilemap) HIPCHK(hipFree(d_tilemap));
+    d_tilemap = nullptr;
+    HIPCHK(hipMalloc(&d_tilemap, tm.size() * sizeof(int)));
+    HIPCHK(hipMemcpy(d_tilemap, tm.data(), tm.size() * sizeof(int), hipMemcpyHostToDevice));
+    tilemap_nt = nt;
+    tilemap_ntc = ntc;
+    return EKF_OK;
   }
 
   // W, S (and nu) for a measured set already resident in d_midx / d_z.
@@ -539,11 +611,10 @@ struct Filter : FilterBase {
     const int m = 2 * M + (plane ? 3 : 0);
     const int m_pad = round_up(m, nb);
     const int npad_live = round_up(n, nb);
-    T* Wp = d_Y + (size_t)ldy * m_pad;
-    T* nu_row = d_Y + (size_t)ldy * (m_pad + npad_live);
+    T* nu_row = d_W + (size_t)ldy * npad_live;
     // pad rows of W (n..npad_live) and the nu block must be zero
     if (npad_live > n)
-      HIPCHK(hipMemsetAsync(Wp + (size_t)n * ldy, 0, (size_t)(npad_live - n) * ldy * sizeof(T), stream));
+      HIPCHK(hipMemsetAsync(d_W + (size_t)n * ldy, 0, (size_t)(npad_live - n) * ldy * sizeof(T), stream));
     HIPCHK(hipMemsetAsync(nu_row, 0, (size_t)nb * ldy * sizeof(T), stream));
     if (with_nu) {
       Scope sc(this, KID_INNOVATION);
@@ -553,14 +624,14 @@ struct Filter : FilterBase {
       Scope sc(this, KID_SIGMA_HT);
       constexpr int RB = 32;
       dim3 grid((m_pad / 2 + 255) / 256, (n + RB - 1) / RB);
-      k_sigma_ht<T, RB><<<grid, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane, Wp, ldy,
+      k_sigma_ht<T, RB><<<grid, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane, d_W, ldy,
                                                 m_pad);
     }
     {
       Scope sc(this, KID_INNOVATION_COV);
       constexpr int KB = 8;
       dim3 grid((m_pad + 255) / 256, std::max(1, (M + KB - 1) / KB));
-      k_innovation_cov<T, KB><<<grid, 256, 0, stream>>>(Wp, ldy, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane,
+      k_innovation_cov<T, KB><<<grid, 256, 0, stream>>>(d_W, ldy, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane,
                                                       T(sigma_pixel_2), T(0.00001), d_Y, m_pad);
     }
     HIPCHK(hipGetLastError());
@@ -590,43 +661,86 @@ struct Filter : FilterBase {
     if (rc) return rc;
     const int nb = NB();
     const int npad_live = round_up(n, nb);
-    const int rows_total = m_pad + npad_live + nb;       // S, W, nu block
     T* Y = d_Y;
-    // tall blocked right-looking Cholesky: [S; W; nu^T] -> [L; W L^-T; (L^-1 nu)^T]
-    for (int j = 0; j < m_pad; j += nb) {
-      T* Ajj = Y + (size_t)j * ldy + j;
-      T* Dj = d_Dinv + (size_t)(j / nb) * nb * nb;
-      {
-        Scope sc(this, KID_CHOL_DIAG);
-        if (nb == 128) {
-          if constexpr (kIsF32)
-            k_chol_diag<T, 128><<<1, 1024, diag_lds(128), stream>>>(Ajj, ldy, Dj, d_status);
-        } else {
-          k_chol_diag<T, 64><<<1, 1024, diag_lds(64), stream>>>(Ajj, ldy, Dj, d_status);
+    T* Z = d_Y + (size_t)m_pad * ldy;
+    {
+      Scope sc(this, KID_MISC);
+      dim3 grid((m_pad + 255) / 256, m_pad);
+      k_set_identity<T><<<grid, 256, 0, stream>>>(Z, ldy, m_pad);
+    }
+    // tall blocked right-looking Cholesky: [S; I] -> [L; Z = L^-T].  At step j the rows that can
+    // change are S rows below the diagonal block plus Z rows of block 0..j: always m_pad rows.
+    // The chain is serial and small; the two large contractions are cut into column groups of
+    // Z / V and run on a second stream as soon as their group of the chain is final:
+    //   solve piece g     V[:, g] = [W; nu^T] Z[:, g]        (K stops at the diagonal)
+    //   downdate piece g  Sigma  -= V[:, g] V[:, g]^T
+    const int nsteps = m_pad / nb;
+    const int ngroups = opt_pipeline ? std::min(4, nsteps) : 1;
+    const int tile = (kIsF32 && opt_mfma) ? 128 : 64;
+    const int ntr = (npad_live + nb) / tile, ntc = m_pad / tile;
+    rc = ensure_tilemap(npad_live / tile, ntr, ntc);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(d_counters, 0, 64 * sizeof(int), stream));
+    counter_next = 0;
+    int step = 0;
+    for (int gi = 0; gi < ngroups; ++gi) {
+      const int step_end = (int)((long long)nsteps * (gi + 1) / ngroups);
+      const int col_begin = step * nb;
+      for (; step < step_end; ++step) {
+        const int j = step * nb;
+        T* Ajj = Y + (size_t)j * ldy + j;
+        T* Dj = d_Dinv + (size_t)step * nb * nb;
+        {
+          Scope sc(this, KID_CHOL_DIAG);
+          if (nb == 128) {
+            if constexpr (kIsF32)
+              k_chol_diag<T, 128><<<1, 512, diag_lds(128), stream>>>(Ajj, ldy, Dj, d_status);
+          } else {
+            k_chol_diag<T, 64><<<1, 512, diag_lds(64), stream>>>(Ajj, ldy, Dj, d_status);
+          }
+        }
+        const int r0 = j + nb;                            // first row below the diagonal block
+        {
+          Scope sc(this, KID_CHOL_PANEL);                 // P = Y[r0:r0+m_pad, j:j+nb] * Linv_jj^T, in place
+          T* P = Y + (size_t)r0 * ldy + j;
+          gemm<ROLE_PANEL, false>(P, ldy, Dj, nb, P, ldy, m_pad, nb, nb, T(1), T(0), 0, 0, 0, 0);
+        }
+        if (r0 < m_pad) {
+          Scope sc(this, KID_CHOL_TRAILING);              // Y[r0:r0+m_pad, r0:m_pad] -= P P_S^T
+          const T* P = Y + (size_t)r0 * ldy + j;
+          T* C = Y + (size_t)r0 * ldy + r0;
+          gemm<ROLE_TRAILING, false>(P, ldy, P, ldy, C, ldy, m_pad, m_pad - r0, nb, T(-1), T(1), 1, r0, r0, 0);
         }
       }
-      const int r0 = j + nb;                              // first row below the diagonal block
-      {
-        Scope sc(this, KID_CHOL_PANEL);                   // P = Y[r0:, j:j+nb] * Linv_jj^T, in place
-        T* P = Y + (size_t)r0 * ldy + j;
-        gemm(P, ldy, Dj, nb, P, ldy, rows_total - r0, nb, nb, T(1), T(0), 0, 0, 0);
+      const int col_end = step * nb;
+      const int width = col_end - col_begin;
+      hipStream_t sb = opt_pipeline ? stream_b : stream;
+      if (opt_pipeline) {
+        HIPCHK(hipEventRecord(ev_chain[gi], stream));
+        HIPCHK(hipStreamWaitEvent(stream_b, ev_chain[gi], 0));
       }
-      if (r0 < m_pad) {
-        Scope sc(this, KID_CHOL_TRAILING);                // Y[r0:, r0:m_pad] -= P P_S^T (lower of S + all of W)
-        const T* P = Y + (size_t)r0 * ldy + j;
-        T* C = Y + (size_t)r0 * ldy + r0;
-        gemm(P, ldy, P, ldy, C, ldy, rows_total - r0, m_pad - r0, nb, T(-1), T(1), 1, r0, r0);
+      {
+        Scope sc(this, KID_SOLVE, sb);                    // column tiles [col_begin, col_end) of V, heaviest first
+        const int c0 = col_begin / tile, c1 = col_end / tile;
+        const int* list = d_tilemap + solve_off + 2 * (ntc - c1) * ntr;
+        gemm<ROLE_SOLVE, true>(d_W, ldy, Z, ldy, d_V, ldy, npad_live + nb, width, m_pad, T(1), T(0), 0, 0, 0, 1, 0,
+                               sb, list, (c1 - c0) * ntr);
+      }
+      {
+        Scope sc(this, KID_DOWNDATE, sb);                 // Sigma -= V_g V_g^T (lower tiles + mirror)
+        gemm<ROLE_DOWNDATE, false>(d_V + col_begin, ldy, d_V + col_begin, ldy, S(), ld, npad_live, npad_live, width,
+                                   T(-1), T(1), 2, 0, 0, 0, 0, sb, d_tilemap, tri_count);
       }
     }
-    const T* V = Y + (size_t)m_pad * ldy;
-    const T* yv = Y + (size_t)(m_pad + npad_live) * ldy;
+    if (opt_pipeline) {
+      HIPCHK(hipEventRecord(ev_b, stream_b));
+      HIPCHK(hipStreamWaitEvent(stream, ev_b, 0));
+    }
+    const T* V = d_V;
+    const T* yv = d_V + (size_t)npad_live * ldy;
     {
       Scope sc(this, KID_STATE_UPDATE);
       k_state_update<T><<<(n + 3) / 4, 256, 0, stream>>>(mu(), V, ldy, n, yv, m_pad);
-    }
-    {
-      Scope sc(this, KID_DOWNDATE);                       // Sigma -= V V^T (lower tiles + mirror)
-      gemm(V, ldy, V, ldy, S(), ld, npad_live, npad_live, m_pad, T(-1), T(1), 2, 0, 0);
     }
     {
       Scope sc(this, KID_NORMALIZE);
@@ -667,20 +781,22 @@ struct Filter : FilterBase {
   int get_gain(void* out) override {
     HIPCHK(hipSetDevice(device));
     if (!have_update) FAIL(EKF_ERR_STATE, "no update to take the gain from");
-    const int m = last_m, nn = last_n;
-    const size_t need = (size_t)nn * m;
+    const int m = last_m, nn = last_n, m_pad = last_m_pad;
+    const int nb = NB();
+    const int npad_live = round_up(nn, nb);
+    const size_t need = (size_t)npad_live * m_pad;
     if (need > K_elems) {
       if (d_K) HIPCHK(hipFree(d_K));
       d_K = nullptr;
       HIPCHK(hipMalloc(&d_K, need * sizeof(T)));
       K_elems = need;
     }
-    const T* V = d_Y + (size_t)last_m_pad * ldy;
-    HIPCHK(hipMemcpy2DAsync(d_K, (size_t)m * sizeof(T), V, (size_t)ldy * sizeof(T), (size_t)m * sizeof(T), nn,
-                            hipMemcpyDeviceToDevice, stream));
-    k_gain_solve<T><<<(nn + 63) / 64, 64, 0, stream>>>(d_K, m, nn, d_Y, ldy, m);
-    std::vector<T> tmp(need);
-    HIPCHK(hipMemcpyAsync(tmp.data(), d_K, need * sizeof(T), hipMemcpyDeviceToHost, stream));
+    // K = V L^-1 = V Z^T: C[i][c] = sum_k V[i][k] Z[c][k]
+    const T* Z = d_Y + (size_t)m_pad * ldy;
+    gemm<ROLE_GAIN, false>(d_V, ldy, Z, ldy, d_K, m_pad, npad_live, m_pad, m_pad, T(1), T(0), 0, 0, 0, 0);
+    std::vector<T> tmp((size_t)nn * m);
+    HIPCHK(hipMemcpy2DAsync(tmp.data(), (size_t)m * sizeof(T), d_K, (size_t)m_pad * sizeof(T), (size_t)m * sizeof(T), nn,
+                            hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     T* o = static_cast<T*>(out);
     for (int r = 0; r < nn; ++r)

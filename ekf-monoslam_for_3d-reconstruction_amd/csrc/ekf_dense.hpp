@@ -1,11 +1,12 @@
 // Dense kernels of the EKF update (a8-a10): W = Sigma H^T from the compact Jacobian,
-// S = H W + R, the tall blocked Cholesky that turns [S; W; nu^T] into [L; V = W L^-T; y^T],
-// the state update mu += V y and the downdate Sigma -= V V^T.
+// S = H W + R, the tall blocked Cholesky that turns [S; I] into [L; Z = L^-T], the solve
+// [V; y^T] = [W; nu^T] Z, the state update mu += V y and the downdate Sigma -= V V^T.
 //
-// Workspace Y (row-major, ldy per row):
-//   rows [0, m_pad)                    S  (m = 2M (+3) live, identity on the padded diagonal)
-//   rows [m_pad, m_pad + n_pad)        W  (row m_pad + i = row i of Sigma H^T; pads zero)
-//   rows [m_pad + n_pad, +NB)          first row nu^T = (z - h)^T, rest zero
+// Workspaces (row-major, ldy per row):
+//   Y  rows [0, m_pad)            S  (m = 2M (+3) live, identity on the padded diagonal)
+//      rows [m_pad, 2 m_pad)      I -> Z = L^-T (upper triangular)
+//   W  rows [0, n_pad)            Sigma H^T (pads zero);  row n_pad: nu^T = (z - h)^T
+//   V  same shape as W            W L^-T;                 row n_pad: y^T = (L^-1 nu)^T
 // All pads are multiples of the GEMM tile, and everything outside the live region is kept
 // zero, so the tile kernels carry no edge guards.
 #pragma once
@@ -142,30 +143,76 @@ __global__ void k_innovation_cov(const T* __restrict__ W, int ldy,
 }
 
 // ---------------------------------------------------------------------------------------
-// Generic tile GEMM  C = beta C + alpha A B^T  (A: rows x K, B: cols x K, both K-contiguous),
-// plain VALU, 64x64 tile, 4x4 per lane.  Serves T = double and the non-MFMA option.
+// Tile GEMMs  C = beta C + alpha A op(B)   (A: rows x K row-major, K-contiguous)
+//   BT = false ("NT"): B is cols x K row-major, C[i][j] = sum_k A[i][k] B[j][k]
+//   BT = true  ("NN"): B is K x cols row-major, C[i][j] = sum_k A[i][k] B[k][j]
 //   tri: 0 = every tile; 1 = skip tiles strictly above the diagonal, the diagonal being
 //        (row_off + i == col_off + j); 2 = as 1 and mirror every strictly-lower tile into
 //        C^T (symmetric rank-K update).
-//   kmode: 0 = full K; 1 = B is lower-triangular in (j,k): k < col_off_k + (bj+1)*64.
-// Dimensions are multiples of 64 (K of 16): no guards.
+//   ktri: 1 = op(B) is upper-triangular in (k, j) (zero for k > j): the K loop of column tile
+//        bj stops at (bj + ktile_off + 1)*TS.
+// ROLE only tags the instantiation so that rocprofv3 lists each use of the tile kernel under
+// its own name (0 panel, 1 trailing, 2 downdate, 3 solve, 4 gain).
+// Dimensions are multiples of the tile (K of the K-step): no guards.
 // ---------------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(256)
-k_gemm_nt_valu(const T* A, int lda, const T* B, int ldb, T* C, int ldc, int K, T alpha, T beta,
-               int tri, int row_off, int col_off) {
+enum : int { ROLE_PANEL = 0, ROLE_TRAILING = 1, ROLE_DOWNDATE = 2, ROLE_SOLVE = 3, ROLE_GAIN = 4 };
+
+struct GemmArgs {
+  const void* A; int lda;
+  const void* B; int ldb;
+  void* C; int ldc;
+  int K;
+  double alpha, beta;
+  int tri, row_off, col_off, ktri, ktile_off;   // ktile_off: global column-tile index of bj = 0
+  // Optional work queue: `ntiles` (bi, bj) pairs in tile_map, drawn through *counter by a
+  // persistent grid (2 workgroups per CU).  The host orders the list heaviest-first (triangular
+  // solve) or in 8x8 super-tiles (downdate: the tiles in flight share their panels in L2), so
+  // the makespan does not depend on how the dispatcher places workgroups.
+  const int* tile_map; int ntiles; int* counter;
+};
+
+// Next tile of this workgroup: plain 2-D grid (one tile, then done) or the work queue.
+__device__ __forceinline__ bool gemm_next_tile(const GemmArgs& g, int* s_tile, int& iter, int& bi, int& bj) {
+  if (!g.tile_map) {
+    if (iter++) return false;
+    bi = blockIdx.y;
+    bj = blockIdx.x;
+    return true;
+  }
+  __syncthreads();                       // everyone is done with the previous tile (and s_tile)
+  if (threadIdx.x == 0) *s_tile = atomicAdd(g.counter, 1);
+  __syncthreads();
+  const int t = *s_tile;
+  if (t >= g.ntiles) return false;
+  bi = g.tile_map[2 * t];
+  bj = g.tile_map[2 * t + 1];
+  ++iter;
+  return true;
+}
+
+template <typename T, int ROLE, bool BT>
+__global__ void __launch_bounds__(256) k_gemm_valu(GemmArgs g) {
   constexpr int TS = 64, BK = 16;
-  const int bi = blockIdx.y, bj = blockIdx.x;
-  const int grow0 = row_off + bi * TS, gcol0 = col_off + bj * TS;
-  if (tri && grow0 + TS <= gcol0) return;
+  const T* A = static_cast<const T*>(g.A);
+  const T* B = static_cast<const T*>(g.B);
+  T* C = static_cast<T*>(g.C);
+  const int lda = g.lda, ldb = g.ldb, ldc = g.ldc;
+  const T alpha = T(g.alpha), beta = T(g.beta);
   __shared__ T As[BK][TS + 4];
   __shared__ T Bs[BK][TS + 4];
+  __shared__ int s_tile;
   const int tid = threadIdx.x;
+  int bi, bj, iter = 0;
+  while (gemm_next_tile(g, &s_tile, iter, bi, bj)) {
+  const int grow0 = g.row_off + bi * TS, gcol0 = g.col_off + bj * TS;
+  if (g.tri && grow0 + TS <= gcol0) continue;
+  const int K = g.ktri ? min(g.K, (bj + g.ktile_off + 1) * TS) : g.K;
   const int tx = tid & 15, ty = tid >> 4;
   const int lr = tid >> 2;            // 0..63 row within tile
   const int lk = (tid & 3) * 4;       // 0,4,8,12
   const T* Ap = A + (size_t)(bi * TS + lr) * lda + lk;
-  const T* Bp = B + (size_t)(bj * TS + lr) * ldb + lk;
+  const T* Bp = BT ? (B + (size_t)(tid >> 4) * ldb + bj * TS + (tid & 15) * 4)
+                   : (B + (size_t)(bj * TS + lr) * ldb + lk);
   T acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -174,10 +221,17 @@ k_gemm_nt_valu(const T* A, int lda, const T* B, int ldb, T* C, int ldc, int K, T
   for (int k0 = 0; k0 < K; k0 += BK) {
     T av[4], bv[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { av[e] = Ap[k0 + e]; bv[e] = Bp[k0 + e]; }
+    for (int e = 0; e < 4; ++e) {
+      av[e] = Ap[k0 + e];
+      bv[e] = BT ? Bp[(size_t)k0 * ldb + e] : Bp[k0 + e];
+    }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { As[lk + e][lr] = av[e]; Bs[lk + e][lr] = bv[e]; }
+    for (int e = 0; e < 4; ++e) {
+      As[lk + e][lr] = av[e];
+      if (BT) Bs[tid >> 4][(tid & 15) * 4 + e] = bv[e];
+      else Bs[lk + e][lr] = bv[e];
+    }
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < BK; ++kk) {
@@ -190,7 +244,7 @@ k_gemm_nt_valu(const T* A, int lda, const T* B, int ldb, T* C, int ldc, int K, T
         for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
     }
   }
-  const bool mirror = (tri == 2) && (grow0 >= gcol0 + TS);
+  const bool mirror = (g.tri == 2) && (grow0 >= gcol0 + TS);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = bi * TS + ty * 4 + i;
@@ -200,55 +254,94 @@ k_gemm_nt_valu(const T* A, int lda, const T* B, int ldb, T* C, int ldc, int K, T
       T v = alpha * acc[i][j];
       if (beta != T(0)) v += beta * C[(size_t)r * ldc + c];
       C[(size_t)r * ldc + c] = v;
-      if (mirror) C[(size_t)(c + col_off - row_off) * ldc + (r + row_off - col_off)] = v;
+      if (mirror) C[(size_t)(c + g.col_off - g.row_off) * ldc + (r + g.row_off - g.col_off)] = v;
     }
   }
+  }  // tile loop
 }
 
 // ---------------------------------------------------------------------------------------
-// f32 MFMA tile GEMM, same contract as k_gemm_nt_valu with a 128x128x32 tile:
+// f32 MFMA tile GEMM, same contract with a 128x128x32 tile:
 // 256 lanes = 4 waves (2x2), each wave 64x64 = 2x2 v_mfma_f32_32x32x2_f32 accumulators.
 // LDS image per operand: [q = k/4][row][4] 16-byte slots, slot = q*128 + (row ^ q): the
 // ds_write_b128 of 8 lanes that share a row and the ds_read_b128 of 32 lanes that share q
 // are both bank-conflict free.  One ds_read_b128 per operand feeds 4 MFMAs: lane half h of
 // MFMA e multiplies k = 8s + 4h + e, the same permutation on A and B, so the sum is exact.
+// NN mode stages B by 4x4 register transposes of row-major [k][col] quads.
 // ---------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ void __launch_bounds__(256)
-k_gemm_nt_mfma(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int K, float alpha, float beta,
-               int tri, int row_off, int col_off) {
+template <int ROLE, bool BT>
+__global__ void __launch_bounds__(256) k_gemm_mfma(GemmArgs g) {
   constexpr int TS = 128, BK = 32, NQ = BK / 4;
-  const int bi = blockIdx.y, bj = blockIdx.x;
-  const int grow0 = row_off + bi * TS, gcol0 = col_off + bj * TS;
-  if (tri && grow0 + TS <= gcol0) return;
+  const float* A = static_cast<const float*>(g.A);
+  const float* B = static_cast<const float*>(g.B);
+  float* C = static_cast<float*>(g.C);
+  const int lda = g.lda, ldb = g.ldb, ldc = g.ldc;
+  const float alpha = float(g.alpha), beta = float(g.beta);
   __shared__ f32x4 lds[2 * NQ * TS];          // A image then B image, 32 KiB
+  __shared__ int s_tile;
   f32x4* As = lds;
   f32x4* Bs = lds + NQ * TS;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  // staging: 1024 float4 per operand, 4 per lane; 8 consecutive lanes cover 128 B of a row
+  int bi, bj, iter = 0;
+  while (gemm_next_tile(g, &s_tile, iter, bi, bj)) {
+  const int grow0 = g.row_off + bi * TS, gcol0 = g.col_off + bj * TS;
+  if (g.tri && grow0 + TS <= gcol0) continue;
+  const int K = g.ktri ? min(g.K, (bj + g.ktile_off + 1) * TS) : g.K;
+  // A staging: 1024 float4 per tile, 4 per lane; 8 consecutive lanes cover 128 B of a row
   const float* Ag[4];
   const float* Bg[4];
-  int sslot[4];
+  int aslot[4], bslot[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int idx = tid + 256 * p;
     const int row = idx >> 3, q = idx & 7;
     Ag[p] = A + (size_t)(bi * TS + row) * lda + q * 4;
-    Bg[p] = B + (size_t)(bj * TS + row) * ldb + q * 4;
-    sslot[p] = q * TS + (row ^ q);
+    aslot[p] = q * TS + (row ^ q);
+    if (!BT) {
+      Bg[p] = B + (size_t)(bj * TS + row) * ldb + q * 4;
+      bslot[p] = aslot[p];
+    } else {
+      // lane owns k-quad qk = tid>>5 and column quad cq = tid&31: rows 4qk+p, 4 columns
+      const int qk = tid >> 5, cq = tid & 31;
+      Bg[p] = B + (size_t)(4 * qk + p) * ldb + bj * TS + 4 * cq;
+      bslot[p] = qk * TS + ((4 * cq + p) ^ qk);
+    }
   }
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   const int h = lane >> 5, l31 = lane & 31;
+  // accumulators start at (beta/alpha) C, so the epilogue is a pure store: the C tile is read
+  // once, up front, under the first operand loads (alpha is never 0)
+  // (the beta test is hoisted out of the element loop: a per-element "load or zero" select makes
+  // hipcc branch around every load and wait for each one)
+  f32x16 acc[2][2];
+  if (beta != 0.f) {
+    const float cscale = beta / alpha;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float* Cp = C + (size_t)(bi * TS + wr * 64 + i * 32 + 4 * h) * ldc + bj * TS + wc * 64 + j * 32 + l31;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = Cp[(size_t)((e & 3) + 8 * (e >> 2)) * ldc];
+      }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] *= cscale;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  }
   f32x4 ra[4], rb[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
@@ -258,13 +351,24 @@ k_gemm_nt_mfma(const float* A, int lda, const float* B, int ldb, float* C, int l
   for (int k0 = 0; k0 < K; k0 += BK) {
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < 4; ++p) { As[sslot[p]] = ra[p]; Bs[sslot[p]] = rb[p]; }
+    for (int p = 0; p < 4; ++p) As[aslot[p]] = ra[p];
+    if (!BT) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) Bs[bslot[p]] = rb[p];
+    } else {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {          // column 4cq+p gets (k0..k3) of that column
+        f32x4 t = {rb[0][p], rb[1][p], rb[2][p], rb[3][p]};
+        Bs[bslot[p]] = t;
+      }
+    }
     __syncthreads();
     if (k0 + BK < K) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         ra[p] = *reinterpret_cast<const f32x4*>(Ag[p] + k0 + BK);
-        rb[p] = *reinterpret_cast<const f32x4*>(Bg[p] + k0 + BK);
+        rb[p] = BT ? *reinterpret_cast<const f32x4*>(Bg[p] + (size_t)(k0 + BK) * ldb)
+                   : *reinterpret_cast<const f32x4*>(Bg[p] + k0 + BK);
       }
     }
 #pragma unroll
@@ -288,7 +392,7 @@ k_gemm_nt_mfma(const float* A, int lda, const float* B, int ldb, float* C, int l
     }
   }
   // epilogue: acc reg e of lane -> row (e&3) + 8*(e>>2) + 4*h, col l31 of the 32x32 tile
-  const bool mirror = (tri == 2) && (grow0 >= gcol0 + TS);
+  const bool mirror = (g.tri == 2) && (grow0 >= gcol0 + TS);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -299,49 +403,71 @@ k_gemm_nt_mfma(const float* A, int lda, const float* B, int ldb, float* C, int l
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int r = rbase + (e & 3) + 8 * (e >> 2) + 4 * h;
-        float x = alpha * acc[i][j][e];
-        if (beta != 0.f) x += beta * C[(size_t)r * ldc + c];
+        const float x = alpha * acc[i][j][e];
         v[e] = x;
         C[(size_t)r * ldc + c] = x;
       }
       if (mirror) {
         // 4 consecutive regs are 4 consecutive rows -> one 16-byte store into the transposed tile
-        float* Ct = C + (size_t)(c + col_off - row_off) * ldc + (row_off - col_off);
+        float* Ct = C + (size_t)(c + g.col_off - g.row_off) * ldc + (g.row_off - g.col_off);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
-          *reinterpret_cast<f32x4*>(Ct + rbase + 8 * g + 4 * h) = o;
+        for (int gq = 0; gq < 4; ++gq) {
+          f32x4 o = {v[4 * gq], v[4 * gq + 1], v[4 * gq + 2], v[4 * gq + 3]};
+          *reinterpret_cast<f32x4*>(Ct + rbase + 8 * gq + 4 * h) = o;
         }
       }
     }
+  }  // tile loop
+}
+
+// [S; I]: identity block under S for the factorisation that also yields L^-T.
+template <typename T>
+__global__ void k_set_identity(T* __restrict__ Z, int ldz, int m_pad) {
+  const int r = blockIdx.y;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < m_pad; c += gridDim.x * blockDim.x)
+    Z[(size_t)r * ldz + c] = (r == c) ? T(1) : T(0);
 }
 
 // ---------------------------------------------------------------------------------------
 // Diagonal block of the blocked Cholesky: factor the NB x NB block A = L L^T in LDS and
 // produce L^-1 in the same sweep by carrying an identity block under A (the tall matrix
-// [A; I] turns into [L; L^-T]).  Inner blocking 16: (1) a 16x16 factor in registers of one
-// wave, (2) the 16-wide panel by row substitution, (3) a register-tiled rank-16 update.
-// One workgroup of 1024 lanes; `status[0]` is raised when a pivot is not positive.
-// Writes L (lower, zeros above) back to A and L^-1 (row-major, lower) to Dinv.
+// [A; I] turns into [L; L^-T]).  Inner blocking 16:
+//   (1) 16x16 factor in the registers of one wave, rows broadcast with v_readlane;
+//   (2) the 16-wide panel by forward substitution, one logical row per lane;
+//   (3) rank-16 update of the trailing columns: v_mfma_f32_16x16x4_f32 tiles for f32
+//       (4 MFMAs per 16x16 tile), register-tiled VALU for f64.
+// At inner step K0 the rows that can change are A rows below the 16-block and I rows
+// 0..K0+15: always NB "logical" rows.  One workgroup of 512 lanes; `status[0]` is raised when
+// a pivot is not positive.  Writes L (lower, zeros above) back to A and L^-1 to Dinv.
 // ---------------------------------------------------------------------------------------
-template <typename T, int NB>
-__global__ void __launch_bounds__(1024)
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ double lane_bcast(double v, int lane) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <typename T, int NB, int MASK = 7>
+__global__ void __launch_bounds__(512)
 k_chol_diag(T* __restrict__ Aglob, int ld, T* __restrict__ Dinv, int* __restrict__ status) {
   constexpr int LDA = NB + 1;
-  constexpr int RT = NB / 32;                      // logical rows per lane in the update
+  constexpr int NT = 512;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* a = reinterpret_cast<T*>(smem_raw);           // [2*NB][LDA]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  for (int idx = tid; idx < NB * NB; idx += blockDim.x) {
+  for (int idx = tid; idx < NB * NB; idx += NT) {
     const int i = idx / NB, j = idx % NB;
     a[i * LDA + j] = Aglob[(size_t)i * ld + j];
     a[(NB + i) * LDA + j] = (i == j) ? T(1) : T(0);
   }
   __syncthreads();
   for (int K0 = 0; K0 < NB; K0 += 16) {
-    // (1) 16x16 diagonal factor, rows in registers of wave 0 (lanes >= 16 mirror lanes & 15)
-    if (wave == 0) {
+    // (1) 16x16 diagonal factor: lane i (< 16) holds row i; column k is broadcast lane by lane
+    if ((MASK & 1) && wave == 0) {
       const int i = lane & 15;
       T r[16];
 #pragma unroll
@@ -349,16 +475,13 @@ k_chol_diag(T* __restrict__ Aglob, int ld, T* __restrict__ Dinv, int* __restrict
       bool bad = false;
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
-        const T pk = __shfl(r[k], k, 16);
+        const T pk = lane_bcast(r[k], k);
         if (!(pk > T(0))) bad = true;
         const T sq = t_sqrt(pk > T(0) ? pk : T(1));
         const T lik = (i == k) ? sq : r[k] / sq;
         r[k] = lik;
 #pragma unroll
-        for (int j = k + 1; j < 16; ++j) {
-          const T ljk = __shfl(lik, j, 16);
-          r[j] -= lik * ljk;
-        }
+        for (int j = k + 1; j < 16; ++j) r[j] -= lik * lane_bcast(lik, j);
       }
       if (bad && lane == 0) status[0] = 1;
       if (lane < 16) {
@@ -370,7 +493,7 @@ k_chol_diag(T* __restrict__ Aglob, int ld, T* __restrict__ Dinv, int* __restrict
     // logical rows: top rows K0+16..NB-1, then bottom rows NB+0..NB+K0+15  (NB - 16 + 16 = NB)
     const int ntop = NB - K0 - 16;
     // (2) panel: p L16^T = y by forward substitution, one logical row per lane
-    if (tid < NB) {
+    if ((MASK & 2) && tid < NB) {
       const int prow = (tid < ntop) ? (K0 + 16 + tid) : (NB + (tid - ntop));
       T y[16];
 #pragma unroll
@@ -386,42 +509,68 @@ k_chol_diag(T* __restrict__ Aglob, int ld, T* __restrict__ Dinv, int* __restrict
       for (int c = 0; c < 16; ++c) a[prow * LDA + K0 + c] = y[c];
     }
     __syncthreads();
-    // (3) rank-16 update of columns K0+16.. for every logical row; lane tile = RT rows x 4 cols
-    const int ncg = ntop / 4;                      // column groups of 4
-    const int l32 = tid & 31, cg = tid >> 5;
-    if (cg < ncg) {
-      int prow[RT];
+    // (3) rank-16 update of columns K0+16.. for every logical row
+    if constexpr (!(MASK & 4)) {
+    } else if constexpr (sizeof(T) == 4) {
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      const int ncb = ntop / 16;                   // 16-column blocks to update
+      const int ntiles = (NB / 16) * ncb;
+      const int lr = lane & 15, lq = lane >> 4;
+      for (int t = wave; t < ntiles; t += NT / 64) {
+        const int rb = t / ncb, cb = t % ncb;
+        const int lrow0 = rb * 16;                 // logical row block; entirely top or bottom
+        const int prow0 = (lrow0 < ntop) ? (K0 + 16 + lrow0) : (NB + (lrow0 - ntop));
+        const int c0 = K0 + 16 + cb * 16;
+        f4 acc;
 #pragma unroll
-      for (int r = 0; r < RT; ++r) {
-        const int lr = l32 + 32 * r;
-        prow[r] = (lr < ntop) ? (K0 + 16 + lr) : (NB + (lr - ntop));
+        for (int e = 0; e < 4; ++e) acc[e] = a[(prow0 + 4 * lq + e) * LDA + c0 + lr];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const float av = -a[(prow0 + lr) * LDA + K0 + 4 * s4 + lq];   // A[row lr][k lq], negated
+          const float bv = a[(c0 + lr) * LDA + K0 + 4 * s4 + lq];       // B[k lq][col lr] = P[c0+lr][k]
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[(prow0 + 4 * lq + e) * LDA + c0 + lr] = acc[e];
       }
-      const int c0 = K0 + 16 + cg * 4;
-      T acc[RT][4];
+    } else {
+      constexpr int RT = NB / 32;                  // logical rows per lane
+      const int ncg = ntop / 4;                    // column groups of 4
+      const int l32 = tid & 31, cg = tid >> 5;
+      if (cg < ncg) {
+        int prow[RT];
 #pragma unroll
-      for (int r = 0; r < RT; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[r][c] = T(0);
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        T pr[RT], pc[4];
-#pragma unroll
-        for (int r = 0; r < RT; ++r) pr[r] = a[prow[r] * LDA + K0 + k];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) pc[c] = a[(c0 + c) * LDA + K0 + k];
+        for (int r = 0; r < RT; ++r) {
+          const int lrw = l32 + 32 * r;
+          prow[r] = (lrw < ntop) ? (K0 + 16 + lrw) : (NB + (lrw - ntop));
+        }
+        const int c0 = K0 + 16 + cg * 4;
+        T acc[RT][4];
 #pragma unroll
         for (int r = 0; r < RT; ++r)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) acc[r][c] += pr[r] * pc[c];
+          for (int c = 0; c < 4; ++c) acc[r][c] = T(0);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          T pr[RT], pc[4];
+#pragma unroll
+          for (int r = 0; r < RT; ++r) pr[r] = a[prow[r] * LDA + K0 + k];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) pc[c] = a[(c0 + c) * LDA + K0 + k];
+#pragma unroll
+          for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][c] += pr[r] * pc[c];
+        }
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) a[prow[r] * LDA + c0 + c] -= acc[r][c];
       }
-#pragma unroll
-      for (int r = 0; r < RT; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) a[prow[r] * LDA + c0 + c] -= acc[r][c];
     }
     __syncthreads();
   }
-  for (int idx = tid; idx < NB * NB; idx += blockDim.x) {
+  for (int idx = tid; idx < NB * NB; idx += NT) {
     const int i = idx / NB, j = idx % NB;
     Aglob[(size_t)i * ld + j] = (j <= i) ? a[i * LDA + j] : T(0);
     // bottom block holds Z = L^-T (upper): Linv[i][j] = Z[j][i]
@@ -444,22 +593,6 @@ __global__ void k_state_update(T* __restrict__ mu, const T* __restrict__ V, int 
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if (lane == 0) mu[row] += acc;
-}
-
-// ---------------------------------------------------------------------------------------
-// Debug/inspection getter: K = V L^-1 by back substitution, one lane per row of K (in place
-// in Kbuf, which starts as a copy of V).  Not on the hot path.
-// ---------------------------------------------------------------------------------------
-template <typename T>
-__global__ void k_gain_solve(T* __restrict__ Kbuf, int ldk, int n, const T* __restrict__ L, int ldy, int m) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= n) return;
-  T* k = Kbuf + (size_t)row * ldk;
-  for (int c = m - 1; c >= 0; --c) {
-    T acc = k[c];
-    for (int j = c + 1; j < m; ++j) acc -= k[j] * L[(size_t)j * ldy + c];
-    k[c] = acc / L[(size_t)c * ldy + c];
-  }
 }
 
 template <typename T>

@@ -69,7 +69,10 @@ enum ekf_option {
   /* 1 (default): hand-written MFMA kernels for the dense contractions; 0: plain VALU tiles. */
   EKF_OPT_USE_MFMA = 1,
   /* profiling level: 0 off, 1 HIP events around the dominant kernels, 2 around every kernel. */
-  EKF_OPT_PROFILE = 2
+  EKF_OPT_PROFILE = 2,
+  /* 1 (default): the solve / downdate contractions are cut into column groups and overlapped
+   * with the serial Cholesky chain on a second stream; 0: one stream, one launch each. */
+  EKF_OPT_PIPELINE = 3
 };
 
 /* Fills `cfg` with the reference defaults (ConfigVSLAM.cpp:27-47, camModel.hpp:22-31). */

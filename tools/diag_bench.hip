@@ -1,0 +1,36 @@
+// Standalone timing of k_chol_diag phases (debug harness; not part of the library).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <cmath>
+#include "../ekf-monoslam_for_3d-reconstruction_amd/csrc/ekf_dense.hpp"
+using namespace ekf;
+template <int MASK> float run(float* dA, float* dA0, float* dD, int* dst, int ld, int reps) {
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_diag<float, 128, MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 129 * 4);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  float tot = 0;
+  for (int r = 0; r < reps; ++r) {
+    hipMemcpy(dA, dA0, (size_t)128 * ld * 4, hipMemcpyDeviceToDevice);
+    hipEventRecord(a);
+    k_chol_diag<float, 128, MASK><<<1, 512, 2 * 128 * 129 * 4>>>(dA, ld, dD, dst);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); if (r) tot += ms;
+  }
+  return tot / (reps - 1) * 1e3f;
+}
+int main() {
+  const int ld = 2048;
+  std::vector<float> h((size_t)128 * ld, 0.f);
+  for (int i = 0; i < 128; ++i) for (int j = 0; j < 128; ++j) h[(size_t)i * ld + j] = (i == j ? 140.f : 0.f) + std::cos(0.37f * i * j + i + j);
+  for (int i = 0; i < 128; ++i) for (int j = 0; j < i; ++j) h[(size_t)j * ld + i] = h[(size_t)i * ld + j];
+  float *dA, *dA0, *dD; int* dst;
+  hipMalloc(&dA, h.size() * 4); hipMalloc(&dA0, h.size() * 4); hipMalloc(&dD, 128 * 128 * 4); hipMalloc(&dst, 16);
+  hipMemcpy(dA0, h.data(), h.size() * 4, hipMemcpyHostToDevice); hipMemset(dst, 0, 16);
+  printf("all      %.2f us\n", run<7>(dA, dA0, dD, dst, ld, 50));
+  printf("none     %.2f us\n", run<0>(dA, dA0, dD, dst, ld, 50));
+  printf("S1 only  %.2f us\n", run<1>(dA, dA0, dD, dst, ld, 50));
+  printf("S2 only  %.2f us\n", run<2>(dA, dA0, dD, dst, ld, 50));
+  printf("S3 only  %.2f us\n", run<4>(dA, dA0, dD, dst, ld, 50));
+  printf("S1+S2    %.2f us\n", run<3>(dA, dA0, dD, dst, ld, 50));
+  return 0;
+}

@@ -13,6 +13,8 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 cfg = pkg.kinect_config()
 px0, z = synthetic.measurement_stream(cfg, N, steps + 3, sigma_px=bench.SIGMA_Z_PX)
 flt = bench.build_filter(pkg, cfg, N, px0)
+pipe = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+flt.set_option(3, pipe)
 dev = torch.device("cuda", 0)
 d_z = torch.from_numpy(z.reshape(z.shape[0], -1)).to(dev).contiguous()
 d_idx = torch.arange(N, dtype=torch.int32, device=dev)

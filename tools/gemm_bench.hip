@@ -1,0 +1,85 @@
+// Standalone timing of the tile GEMM (debug harness; not part of the library).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <cstdlib>
+#include "../ekf-monoslam_for_3d-reconstruction_amd/csrc/ekf_dense.hpp"
+using namespace ekf;
+static std::vector<int> tilemap(int nt) {
+  std::vector<int> tm; const int SB = 8; const int ns = (nt + SB - 1) / SB;
+  for (int si = 0; si < ns; ++si) for (int sj = 0; sj <= si; ++sj)
+    for (int i = si * SB; i < std::min(nt, (si + 1) * SB); ++i)
+      for (int j = sj * SB; j < std::min(nt, (sj + 1) * SB); ++j) if (j <= i) { tm.push_back(i); tm.push_back(j); }
+  return tm;
+}
+static int* g_counters = nullptr;
+template <int ROLE, bool BT> float timeit(GemmArgs g, dim3 grid, int reps) {
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  if (!g_counters) hipMalloc(&g_counters, 64 * 4);
+  hipMemset(g_counters, 0, 64 * 4);
+  if (g.tile_map) { g.counter = g_counters; grid = dim3(std::min(g.ntiles, 512), 1); }
+  k_gemm_mfma<ROLE, BT><<<grid, 256>>>(g); hipDeviceSynchronize();
+  hipEventRecord(a);
+  for (int r = 0; r < reps; ++r) { if (g.tile_map) g.counter = g_counters + 1 + r; k_gemm_mfma<ROLE, BT><<<grid, 256>>>(g); }
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b); return ms / reps;
+}
+int main() {
+  const int n = 6144, ldy = 2048, ld = 6144;
+  float *V, *S, *Z;
+  hipMalloc(&V, (size_t)(n + 128) * ldy * 4); hipMalloc(&S, (size_t)(n + 128) * ld * 4); hipMalloc(&Z, (size_t)ldy * ldy * 4);
+  std::vector<float> h((size_t)(n + 128) * ldy); for (auto& x : h) x = (rand() % 2001 - 1000) * 1e-3f;
+  hipMemcpy(V, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(Z, h.data(), (size_t)ldy * ldy * 4, hipMemcpyHostToDevice);
+  hipMemset(S, 0, (size_t)(n + 128) * ld * 4);
+  auto tm = tilemap(n / 128); int* dtm; hipMalloc(&dtm, tm.size() * 4); hipMemcpy(dtm, tm.data(), tm.size() * 4, hipMemcpyHostToDevice);
+  const int nt = (int)tm.size() / 2;
+  for (int K : {2048, 512}) {
+    GemmArgs g{V, ldy, V, ldy, S, ld, K, -1.0, 1.0, 2, 0, 0, 0, 0, nullptr, 0, nullptr};
+    float t1 = timeit<ROLE_DOWNDATE, false>(g, dim3(n / 128, n / 128), 10);
+    g.tile_map = dtm; g.ntiles = nt;
+    float t2 = timeit<ROLE_DOWNDATE, false>(g, dim3(nt, 1), 10);
+    double flop = (double)n * n * K;   // symmetric half
+    printf("SYRK K=%4d  plain grid %.3f ms (%.1f TF)   tilemap %.3f ms (%.1f TF)\n", K, t1, flop / t1 / 1e9, t2, flop / t2 / 1e9);
+    g.tri = 1;
+    float t4 = timeit<ROLE_DOWNDATE, false>(g, dim3(nt, 1), 10);
+    printf("SYRK K=%4d  tilemap, no mirror %.3f ms (%.1f TF)\n", K, t4, flop / t4 / 1e9);
+    GemmArgs f{V, ldy, V, ldy, S, ld, K, -1.0, 1.0, 0, 0, 0, 0, 0, nullptr, 0, nullptr};
+    float t3 = timeit<ROLE_GAIN, false>(f, dim3(n / 128, n / 128), 5);
+    printf("full GEMM NT K=%4d %.3f ms (%.1f TF)\n", K, t3, 2.0 * n * n * K / t3 / 1e9);
+  }
+  { // solve: (n+128) x 2048 x 2048 NN triangular
+    GemmArgs g{V, ldy, Z, ldy, S, ld, 2048, 1.0, 0.0, 0, 0, 0, 1, 0, nullptr, 0, nullptr};
+    float t = timeit<ROLE_SOLVE, true>(g, dim3(2048 / 128, (n + 128) / 128), 10);
+    printf("solve NN tri %.3f ms (%.1f TF of n*m^2)\n", t, (double)(n + 128) * 2048 * 2048 / t / 1e9 * (17.0/16));
+    {
+      std::vector<int> lm; const int ntr = (n + 128) / 128, ntc = 16;
+      for (int j = ntc - 1; j >= 0; --j) for (int i = 0; i < ntr; ++i) { lm.push_back(i); lm.push_back(j); }
+      int* dl; hipMalloc(&dl, lm.size() * 4); hipMemcpy(dl, lm.data(), lm.size() * 4, hipMemcpyHostToDevice);
+      GemmArgs gl = g; gl.tile_map = dl; gl.ntiles = (int)lm.size() / 2;
+      float tl = timeit<ROLE_SOLVE, true>(gl, dim3(gl.ntiles, 1), 10);
+      printf("solve NN tri, heavy-first tile list %.3f ms (%.1f TF of n*m^2)\n", tl, (double)(n + 128) * 2048 * 2048 / tl / 1e9 * (17.0/16));
+    }
+    for (int off : {0, 3, 7, 15}) {
+      GemmArgs gc = g; gc.ktile_off = off; gc.B = Z + off * 128; gc.C = S + off * 128;
+      float tc = timeit<ROLE_SOLVE, true>(gc, dim3(1, (n + 128) / 128), 10);
+      printf("solve single column tile off=%2d (K=%4d): %.3f ms\n", off, (off + 1) * 128, tc);
+    }
+    g.ktri = 0;
+    t = timeit<ROLE_SOLVE, true>(g, dim3(2048 / 128, (n + 128) / 128), 10);
+    printf("solve NN full %.3f ms (%.1f TF)\n", t, 2.0 * (n + 128) * 2048 * 2048 / t / 1e9);
+    GemmArgs g2{V, ldy, Z, ldy, S, ld, 2048, 1.0, 0.0, 0, 0, 0, 0, 0, nullptr, 0, nullptr};
+    t = timeit<ROLE_GAIN, false>(g2, dim3(2048 / 128, (n + 128) / 128), 10);
+    printf("same shape NT full %.3f ms (%.1f TF)\n", t, 2.0 * (n + 128) * 2048 * 2048 / t / 1e9);
+  }
+  { // chain-shaped GEMMs, K = 128
+    for (int cols : {128, 1024, 1920}) {
+      for (int beta = 0; beta < 2; ++beta) for (int tri = 0; tri < 2; ++tri) {
+        GemmArgs g{V, ldy, V + 128, ldy, S, ld, 128, -1.0, (double)beta, tri, 0, 0, 0, 0, nullptr, 0, nullptr};
+        float t = timeit<ROLE_TRAILING, false>(g, dim3(cols / 128, 2048 / 128), 20);
+        printf("K=128 rows=2048 cols=%4d beta=%d tri=%d: %.1f us\n", cols, beta, tri, t * 1e3);
+      }
+    }
+  }
+  return 0;
+}
