@@ -102,8 +102,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("EKF_BENCH_BACKEND", "nccl")      # "gloo": rehearsal with ranks sharing one GPU
+        ndev = torch.cuda.device_count()
+        local_rank = local_rank % max(ndev, 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
 
     n_feat = args.features

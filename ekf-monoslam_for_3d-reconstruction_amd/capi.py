@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libekfslam_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "ekf_monoslam.h")
 
 EKF_F32, EKF_F64 = 0, 1
-EKF_OPT_PROPAGATE_STREAMING, EKF_OPT_USE_MFMA, EKF_OPT_PROFILE = 0, 1, 2
+EKF_OPT_PROPAGATE_STREAMING, EKF_OPT_USE_MFMA, EKF_OPT_PROFILE, EKF_OPT_PIPELINE = 0, 1, 2, 3
 STATUS_NAMES = {0: "EKF_OK", 1: "EKF_ERR_ARG", 2: "EKF_ERR_CAPACITY", 3: "EKF_ERR_DEVICE",
                 4: "EKF_ERR_STATE", 5: "EKF_ERR_NUMERIC", 6: "EKF_ERR_UNSUPPORTED"}
 
@@ -83,6 +83,12 @@ _PROTOS = {
     "ekf_profile_kernel_name": (C.c_char_p, [C.c_int]),
     "ekf_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "ekf_profile_reset": (C.c_int, [_P]),
+    "ekf_shard_configure": (C.c_int, [_P, C.c_int, C.c_int]),
+    "ekf_shard_get_view": (C.c_int, [_P, _P]),
+    "ekf_shard_predict": (C.c_int, [_P, _P, _P, C.c_int]),
+    "ekf_shard_innovation": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "ekf_shard_factor_solve": (C.c_int, [_P]),
+    "ekf_shard_downdate": (C.c_int, [_P]),
     "ekf_device_mu": (_P, [_P]),
     "ekf_device_sigma": (_P, [_P, C.POINTER(C.c_int)]),
 }

@@ -77,6 +77,12 @@ struct FilterBase {
   virtual int profile_reset() = 0;
   virtual void* dev_mu() = 0;
   virtual void* dev_sigma(int*) = 0;
+  virtual int shard_configure(int, int) = 0;
+  virtual int shard_view(ekf_shard_view*) = 0;
+  virtual int shard_predict(const void*, const void*, int) = 0;
+  virtual int shard_innovation(const void*, int, int) = 0;
+  virtual int shard_factor_solve() = 0;
+  virtual int shard_downdate() = 0;
 };
 
 #define HIPCHK(expr)                                                                         \
@@ -142,7 +148,7 @@ struct Filter : FilterBase {
   bool own_stream = false;
   hipStream_t stream_b = nullptr;                       // overlaps solve / downdate pieces with the chain
   hipEvent_t ev_chain[8] = {}, ev_b = nullptr;
-  int opt_pipeline = 1;
+  int opt_pipeline = 0;
   int* d_tilemap = nullptr;                             // work lists: [lower-tri super-tiles | solve heavy-first]
   int tilemap_nt = 0, tilemap_ntc = 0, tri_count = 0, solve_off = 0;
   int* d_counters = nullptr;                            // one work-queue head per queued launch of an update
@@ -486,7 +492,7 @@ struct Filter : FilterBase {
     if (rc) return rc;
     if (N > 0) {
       Scope sc(this, KID_MEASURE);
-      k_measure<T><<<(N + 63) / 64, 64, 0, stream>>>(mu(), S(), ld, d_pos, d_coding, N, cam, T(sigma_pixel_2), d_h,
+      k_measure<T><<<(N + 63) / 64, 64, 0, stream>>>(mu(), S(), ld, d_pos, d_coding, 0, N, cam, T(sigma_pixel_2), d_h,
                                                     d_Hc, d_Hf, d_flags, d_Sd);
     }
     HIPCHK(hipGetLastError());
@@ -625,14 +631,14 @@ struct Filter : FilterBase {
       constexpr int RB = 32;
       dim3 grid((m_pad / 2 + 255) / 256, (n + RB - 1) / RB);
       k_sigma_ht<T, RB><<<grid, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane, d_W, ldy,
-                                                m_pad);
+                                                m_pad, 0, n);
     }
     {
       Scope sc(this, KID_INNOVATION_COV);
       constexpr int KB = 8;
       dim3 grid((m_pad + 255) / 256, std::max(1, (M + KB - 1) / KB));
       k_innovation_cov<T, KB><<<grid, 256, 0, stream>>>(d_W, ldy, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane,
-                                                      T(sigma_pixel_2), T(0.00001), d_Y, m_pad);
+                                                      T(sigma_pixel_2), T(0.00001), d_Y, m_pad, 0, M);
     }
     HIPCHK(hipGetLastError());
     *m_out = m;
@@ -872,6 +878,181 @@ struct Filter : FilterBase {
     if (c) for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) c[b * 3 + a] = o[3 + a * 3 + b];
     return EKF_OK;
   }
+  // ---- multi-GPU row-panel sharding ------------------------------------------------
+  int sh_rank = 0, sh_world = 1, sh_f0 = 0, sh_f1 = 0, sh_r0 = 0, sh_r1 = 0, sh_p0 = 0, sh_prows = 0;
+  int sh_m = 0, sh_m_pad = 0, sh_plane = 0, sh_stage = 0;
+
+  int shard_configure(int rank, int world) override {
+    if (world < 1 || rank < 0 || rank >= world) FAIL(EKF_ERR_ARG, "bad rank / world");
+    if (N == 0 || N % world != 0) FAIL(EKF_ERR_UNSUPPORTED, "sharding needs N > 0 divisible by the world size");
+    for (int i = 0; i < N; ++i)
+      if (coding[i] != 0) FAIL(EKF_ERR_UNSUPPORTED, "sharding supports inverse-depth features only (round 1)");
+    sh_rank = rank; sh_world = world;
+    sh_f0 = N / world * rank; sh_f1 = N / world * (rank + 1);
+    sh_r0 = pos[sh_f0]; sh_r1 = sh_r0 + 6 * (sh_f1 - sh_f0);
+    const int nb = NB();
+    // tile-padded row panel [sh_p0, sh_p0 + sh_prows): covers the own rows and possibly a few foreign
+    // ones (whose results nobody reads).  A panel that starts inside the first tile is extended to
+    // row 0 so that it never half-overlaps the replicated camera tile.
+    sh_prows = round_up(sh_r1 - sh_r0, nb);
+    sh_p0 = std::min(sh_r0, n_pad - sh_prows);
+    if (sh_p0 < nb) { sh_p0 = 0; sh_prows = round_up(sh_r1, nb); }
+    if (sh_p0 < 0 || sh_p0 + sh_prows > n_pad) FAIL(EKF_ERR_UNSUPPORTED, "panel does not fit");
+    sh_stage = 0;
+    return EKF_OK;
+  }
+  int shard_view(ekf_shard_view* v) override {
+    if (!v) FAIL(EKF_ERR_ARG, "null view");
+    v->rank = sh_rank; v->world = sh_world; v->N = N; v->f_begin = sh_f0; v->f_end = sh_f1;
+    v->camera_dim = camera_dim; v->rows_per_rank = sh_r1 - sh_r0;
+    v->m = sh_m; v->m_pad = sh_m_pad; v->ldy = ldy;
+    v->d_h = d_h; v->d_Hc = d_Hc; v->d_Hf = d_Hf; v->d_flags = d_flags; v->d_S = d_Y; v->d_V = d_V;
+    return EKF_OK;
+  }
+  int shard_predict(const void* tc, const void* rc_, int vcontrol) override {
+    HIPCHK(hipSetDevice(device));
+    if (sh_f1 <= sh_f0) FAIL(EKF_ERR_STATE, "ekf_shard_configure first");
+    MotionArgs a;
+    a.dT = dT;
+    const T* t = static_cast<const T*>(tc);
+    const T* r = static_cast<const T*>(rc_);
+    for (int i = 0; i < 3; ++i) { a.t_ctl[i] = t ? double(t[i]) : 0.0; a.r_ctl[i] = r ? double(r[i]) : 0.0; }
+    for (int i = 0; i < 6; ++i) a.vdiag[i] = vcontrol ? vmax[i] : double(T(vmax[i]) * T(2));
+    int rc = sync_layout();
+    if (rc) return rc;
+    { Scope sc(this, KID_PREDICT_CAMERA); k_predict_camera<T><<<1, 64, 0, stream>>>(mu(), d_scr, a); }
+    {
+      // rows 0..12 are replicated; the column strip of foreign rows works on stale data nobody reads
+      Scope sc(this, KID_PROPAGATE_STRIPS);
+      k_strip_congruence<T, 13><<<(2 * n + 255) / 256, 256, 0, stream>>>(S(), ld, n, 0, d_scr + SCR_FT, d_scr + SCR_Q);
+    }
+    {
+      Scope sc(this, KID_MEASURE);
+      const int cnt = sh_f1 - sh_f0;
+      k_measure<T><<<(cnt + 63) / 64, 64, 0, stream>>>(mu(), S(), ld, d_pos, d_coding, sh_f0, sh_f1, cam,
+                                                        T(sigma_pixel_2), d_h, d_Hc, d_Hf, d_flags, d_Sd);
+    }
+    HIPCHK(hipGetLastError());
+    have_update = false;
+    have_meas = false;
+    sh_stage = 1;
+    return EKF_OK;
+  }
+  int shard_innovation(const void* dz, int M, int plane) override {
+    HIPCHK(hipSetDevice(device));
+    if (sh_stage != 1) FAIL(EKF_ERR_STATE, "ekf_shard_innovation follows ekf_shard_predict (+ gather of h / H)");
+    if (M != N) FAIL(EKF_ERR_UNSUPPORTED, "sharded update measures every feature (M = N) in round 1");
+    HIPCHK(hipMemcpyAsync(d_z, dz, (size_t)2 * M * sizeof(T), hipMemcpyDeviceToDevice, stream));
+    std::vector<int> ident(M);
+    for (int i = 0; i < M; ++i) ident[i] = i;
+    HIPCHK(hipMemcpyAsync(d_midx, ident.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    const int nb = NB();
+    const int m = 2 * M + (plane ? 3 : 0);
+    const int m_pad = round_up(m, nb);
+    const int npad_live = round_up(n, nb);
+    T* nu_row = d_W + (size_t)ldy * npad_live;
+    if (npad_live > n)
+      HIPCHK(hipMemsetAsync(d_W + (size_t)n * ldy, 0, (size_t)(npad_live - n) * ldy * sizeof(T), stream));
+    HIPCHK(hipMemsetAsync(nu_row, 0, (size_t)nb * ldy * sizeof(T), stream));
+    { Scope sc(this, KID_INNOVATION);
+      k_innovation<T><<<(m_pad + 255) / 256, 256, 0, stream>>>(d_z, d_h, d_midx, M, plane, mu(), nu_row, m_pad); }
+    {
+      Scope sc(this, KID_SIGMA_HT);
+      constexpr int RB = 32;
+      dim3 g1((m_pad / 2 + 255) / 256, (camera_dim + RB - 1) / RB);
+      k_sigma_ht<T, RB><<<g1, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane, d_W, ldy,
+                                              m_pad, 0, camera_dim);
+      dim3 g2((m_pad / 2 + 255) / 256, (sh_r1 - sh_r0 + RB - 1) / RB);
+      k_sigma_ht<T, RB><<<g2, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane, d_W, ldy,
+                                              m_pad, sh_r0, sh_r1);
+    }
+    {
+      Scope sc(this, KID_INNOVATION_COV);
+      constexpr int KB = 8;
+      dim3 grid((m_pad + 255) / 256, std::max(1, (sh_f1 - sh_f0 + KB - 1) / KB));
+      k_innovation_cov<T, KB><<<grid, 256, 0, stream>>>(d_W, ldy, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane,
+                                                      T(sigma_pixel_2), T(0.00001), d_Y, m_pad, sh_f0, sh_f1);
+    }
+    HIPCHK(hipGetLastError());
+    sh_m = m; sh_m_pad = m_pad; sh_plane = plane;
+    sh_stage = 2;
+    return EKF_OK;
+  }
+  int shard_factor_solve() override {
+    HIPCHK(hipSetDevice(device));
+    if (sh_stage != 2) FAIL(EKF_ERR_STATE, "ekf_shard_factor_solve follows ekf_shard_innovation (+ gather of S)");
+    const int nb = NB();
+    const int m_pad = sh_m_pad;
+    const int npad_live = round_up(n, nb);
+    T* Y = d_Y;
+    T* Z = d_Y + (size_t)m_pad * ldy;
+    { Scope sc(this, KID_MISC);
+      dim3 grid((m_pad + 255) / 256, m_pad);
+      k_set_identity<T><<<grid, 256, 0, stream>>>(Z, ldy, m_pad); }
+    for (int j = 0, step = 0; j < m_pad; j += nb, ++step) {
+      T* Ajj = Y + (size_t)j * ldy + j;
+      T* Dj = d_Dinv + (size_t)step * nb * nb;
+      { Scope sc(this, KID_CHOL_DIAG);
+        if (nb == 128) {
+          if constexpr (kIsF32) k_chol_diag<T, 128><<<1, 512, diag_lds(128), stream>>>(Ajj, ldy, Dj, d_status);
+        } else {
+          k_chol_diag<T, 64><<<1, 512, diag_lds(64), stream>>>(Ajj, ldy, Dj, d_status);
+        } }
+      const int r0 = j + nb;
+      { Scope sc(this, KID_CHOL_PANEL);
+        T* P = Y + (size_t)r0 * ldy + j;
+        gemm<ROLE_PANEL, false>(P, ldy, Dj, nb, P, ldy, m_pad, nb, nb, T(1), T(0), 0, 0, 0, 0); }
+      if (r0 < m_pad) {
+        Scope sc(this, KID_CHOL_TRAILING);
+        const T* P = Y + (size_t)r0 * ldy + j;
+        T* C = Y + (size_t)r0 * ldy + r0;
+        gemm<ROLE_TRAILING, false>(P, ldy, P, ldy, C, ldy, m_pad, m_pad - r0, nb, T(-1), T(1), 1, r0, r0, 0);
+      }
+    }
+    {
+      Scope sc(this, KID_SOLVE);
+      // camera tile (rows 0..nb-1; only rows < camera_dim are meaningful on this rank), own panel, nu block
+      if (sh_p0 > 0) gemm<ROLE_SOLVE, true>(d_W, ldy, Z, ldy, d_V, ldy, nb, m_pad, m_pad, T(1), T(0), 0, 0, 0, 1);
+      gemm<ROLE_SOLVE, true>(d_W + (size_t)sh_p0 * ldy, ldy, Z, ldy, d_V + (size_t)sh_p0 * ldy, ldy, sh_prows, m_pad,
+                             m_pad, T(1), T(0), 0, 0, 0, 1);
+      gemm<ROLE_SOLVE, true>(d_W + (size_t)npad_live * ldy, ldy, Z, ldy, d_V + (size_t)npad_live * ldy, ldy, nb, m_pad,
+                             m_pad, T(1), T(0), 0, 0, 0, 1);
+    }
+    HIPCHK(hipGetLastError());
+    sh_stage = 3;
+    return EKF_OK;
+  }
+  int shard_downdate() override {
+    HIPCHK(hipSetDevice(device));
+    if (sh_stage != 3) FAIL(EKF_ERR_STATE, "ekf_shard_downdate follows ekf_shard_factor_solve (+ gather of V)");
+    const int nb = NB();
+    const int m_pad = sh_m_pad;
+    const int npad_live = round_up(n, nb);
+    const T* V = d_V;
+    const T* yv = d_V + (size_t)npad_live * ldy;
+    { Scope sc(this, KID_STATE_UPDATE);
+      k_state_update<T><<<(n + 3) / 4, 256, 0, stream>>>(mu(), V, ldy, n, yv, m_pad); }
+    {
+      Scope sc(this, KID_DOWNDATE);     // own row panel and the replicated camera tile, all columns
+      gemm<ROLE_DOWNDATE, false>(V + (size_t)sh_p0 * ldy, ldy, V, ldy, S() + (size_t)sh_p0 * ld, ld, sh_prows, npad_live,
+                                 m_pad, T(-1), T(1), 0, 0, 0, 0);
+      if (sh_p0 > 0)   // a panel that starts at row 0 already contains the camera tile
+        gemm<ROLE_DOWNDATE, false>(V, ldy, V, ldy, S(), ld, nb, npad_live, m_pad, T(-1), T(1), 0, 0, 0, 0);
+    }
+    {
+      Scope sc(this, KID_NORMALIZE);
+      k_normalize_quat<T><<<1, 64, 0, stream>>>(mu(), d_scr);
+      k_strip_congruence<T, 4><<<(2 * n + 255) / 256, 256, 0, stream>>>(S(), ld, n, 3, d_scr + SCR_QN,
+                                                                       static_cast<const T*>(nullptr));
+    }
+    HIPCHK(hipGetLastError());
+    last_m = sh_m; last_m_pad = m_pad; last_n = n;
+    have_update = true;
+    sh_stage = 0;
+    return EKF_OK;
+  }
+
   int profile_read(int kid, double* ms, long long* cnt) override {
     if (kid < 0 || kid >= KID_COUNT) FAIL(EKF_ERR_ARG, "kernel id out of range");
     hipSetDevice(device);
@@ -1027,6 +1208,13 @@ int ekf_profile_kernels(void) { return ekf::KID_COUNT; }
 const char* ekf_profile_kernel_name(int kid) { return (kid >= 0 && kid < ekf::KID_COUNT) ? ekf::kKernelNames[kid] : ""; }
 int ekf_profile_read(ekf_filter* f, int kid, double* ms, long long* cnt) { IMPL_OR_ARG(f); return f->impl->profile_read(kid, ms, cnt); }
 int ekf_profile_reset(ekf_filter* f) { IMPL_OR_ARG(f); return f->impl->profile_reset(); }
+
+int ekf_shard_configure(ekf_filter* f, int rank, int world) { IMPL_OR_ARG(f); return f->impl->shard_configure(rank, world); }
+int ekf_shard_get_view(ekf_filter* f, ekf_shard_view* out) { IMPL_OR_ARG(f); return f->impl->shard_view(out); }
+int ekf_shard_predict(ekf_filter* f, const void* t, const void* r, int vc) { IMPL_OR_ARG(f); return f->impl->shard_predict(t, r, vc); }
+int ekf_shard_innovation(ekf_filter* f, const void* dz, int M, int plane) { IMPL_OR_ARG(f); if (!dz) return EKF_ERR_ARG; return f->impl->shard_innovation(dz, M, plane); }
+int ekf_shard_factor_solve(ekf_filter* f) { IMPL_OR_ARG(f); return f->impl->shard_factor_solve(); }
+int ekf_shard_downdate(ekf_filter* f) { IMPL_OR_ARG(f); return f->impl->shard_downdate(); }
 
 void* ekf_device_mu(ekf_filter* f) { return f ? f->impl->dev_mu() : nullptr; }
 void* ekf_device_sigma(ekf_filter* f, int* ld) { return f ? f->impl->dev_sigma(ld) : nullptr; }

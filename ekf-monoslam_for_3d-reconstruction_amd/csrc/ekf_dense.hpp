@@ -44,12 +44,12 @@ __global__ void k_sigma_ht(const T* __restrict__ S, int ld, int n,
                            const T* __restrict__ Hc, const T* __restrict__ Hf,
                            const int* __restrict__ pos, const int* __restrict__ coding,
                            const int* __restrict__ midx, int M, int plane,
-                           T* __restrict__ W, int ldy, int m_pad) {
+                           T* __restrict__ W, int ldy, int m_pad, int row_begin, int row_end) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;    // measurement slot
-  const int row0 = blockIdx.y * RB;
+  const int row0 = row_begin + blockIdx.y * RB;           // rows [row_begin, row_end) of Sigma
   const int nslots = m_pad / 2;
   if (k >= nslots) return;
-  const int row1 = min(row0 + RB, n);
+  const int row1 = min(row0 + RB, min(row_end, n));
   if (k < M) {
     const int fi = midx[k];
     const int p = pos[fi];
@@ -100,15 +100,15 @@ __global__ void k_innovation_cov(const T* __restrict__ W, int ldy,
                                  const T* __restrict__ Hc, const T* __restrict__ Hf,
                                  const int* __restrict__ pos, const int* __restrict__ coding,
                                  const int* __restrict__ midx, int M, int plane, T r_pix, T r_plane,
-                                 T* __restrict__ Sm, int m_pad) {
+                                 T* __restrict__ Sm, int m_pad, int k_begin, int k_end) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= m_pad) return;
   const int m = 2 * M + (plane ? 3 : 0);
   T wc[7];
 #pragma unroll
   for (int t = 0; t < 7; ++t) wc[t] = W[(size_t)t * ldy + c];
-  const int k0 = blockIdx.y * KB;
-  for (int k = k0; k < min(k0 + KB, M); ++k) {
+  const int k0 = k_begin + blockIdx.y * KB;               // measured features [k_begin, k_end)
+  for (int k = k0; k < min(k0 + KB, k_end); ++k) {
     const int fi = midx[k];
     const int p = pos[fi];
     const int fs = coding[fi] ? 3 : 6;

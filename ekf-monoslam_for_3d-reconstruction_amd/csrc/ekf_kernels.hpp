@@ -245,11 +245,11 @@ __global__ void k_propagate_streaming(const T* __restrict__ src, T* __restrict__
 // ---------------------------------------------------------------------------------------
 template <typename T>
 __global__ void k_measure(const T* __restrict__ mu, const T* __restrict__ S, int ld,
-                          const int* __restrict__ pos, const int* __restrict__ coding, int N,
+                          const int* __restrict__ pos, const int* __restrict__ coding, int f_begin, int N,
                           CamParams cam, T r_pix,
                           T* __restrict__ h_out, T* __restrict__ Hc, T* __restrict__ Hf,
                           unsigned char* __restrict__ flags, T* __restrict__ Sd) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = f_begin + blockIdx.x * blockDim.x + threadIdx.x;   // features [f_begin, N)
   if (i >= N) return;
   const int p = pos[i];
   const bool xyz = coding[i] != 0;

@@ -70,8 +70,8 @@ enum ekf_option {
   EKF_OPT_USE_MFMA = 1,
   /* profiling level: 0 off, 1 HIP events around the dominant kernels, 2 around every kernel. */
   EKF_OPT_PROFILE = 2,
-  /* 1 (default): the solve / downdate contractions are cut into column groups and overlapped
-   * with the serial Cholesky chain on a second stream; 0: one stream, one launch each. */
+  /* 1: the solve / downdate contractions are cut into column groups and overlapped with the
+   * serial Cholesky chain on a second stream; 0 (default): one stream, one launch each. */
   EKF_OPT_PIPELINE = 3
 };
 
@@ -172,6 +172,37 @@ int ekf_profile_kernels(void);
 const char* ekf_profile_kernel_name(int kernel_id);
 int ekf_profile_read(ekf_filter* f, int kernel_id, double* total_ms, long long* launches);
 int ekf_profile_reset(ekf_filter* f);
+
+/* ---- multi-GPU: row-panel sharding, one process per GPU --------------------
+ * Every rank holds the same feature list; rank g owns features [N g/G, N (g+1)/G) and keeps the
+ * rows of Sigma of those features (all columns) plus a replica of the camera rows up to date.
+ * A step is four local phases separated by all-gathers of disjoint panels, which the host does
+ * with RCCL (torch.distributed) on the buffers of `ekf_shard_view`:
+ *   ekf_shard_predict      camera step + strips; h / H / flags of the OWN features
+ *       -> all-gather h, Hc, Hf, flags (per-feature slices)                  "reassemble H"
+ *   ekf_shard_innovation   nu; W = Sigma H^T rows {camera, own}; S rows of the own features
+ *       -> all-gather the row panels of S                                     "reassemble S"
+ *   ekf_shard_factor_solve Cholesky chain of S (replicated), V = W L^-T rows {camera, own}, y
+ *       -> all-gather the row panels of V
+ *   ekf_shard_downdate     mu += V y; Sigma[own rows, :] -= V[own rows] V^T; normalisation
+ * Round-1 limits: inverse-depth features only, N divisible by the world size, every feature
+ * measured (M = N, identity index list) -- anything else returns EKF_ERR_UNSUPPORTED. */
+typedef struct ekf_shard_view {
+  int rank, world, N, f_begin, f_end;     /* own feature range                                  */
+  int camera_dim, rows_per_rank;          /* own Sigma / W / V rows: camera_dim + rank * rows_per_rank ... */
+  int m, m_pad, ldy;                      /* rows of S (2M (+3)), padded, leading dimension      */
+  void* d_h;  void* d_Hc;  void* d_Hf;    /* per-feature arrays: 2, 14, 12 scalars per feature   */
+  unsigned char* d_flags;                 /* 1 byte per feature                                  */
+  void* d_S;                              /* S, row-major, ldy per row; own rows = 2*f_begin ... */
+  void* d_V;                              /* V, row-major, ldy per row                           */
+} ekf_shard_view;
+
+int ekf_shard_configure(ekf_filter* f, int rank, int world);
+int ekf_shard_get_view(ekf_filter* f, ekf_shard_view* out);
+int ekf_shard_predict(ekf_filter* f, const void* t_ctl, const void* r_ctl, int vcontrol);
+int ekf_shard_innovation(ekf_filter* f, const void* d_z, int M, int plane_constraint);
+int ekf_shard_factor_solve(ekf_filter* f);
+int ekf_shard_downdate(ekf_filter* f);
 
 /* Raw device pointers for zero-copy plumbing (torch / RCCL): mu, the live Sigma buffer,
  * and its leading dimension (device storage is row-major, ld elements per row). */
