@@ -661,6 +661,7 @@ struct Filter : FilterBase {
       const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
       HIPCHK(hipMemcpyAsync(d_z, z, (size_t)2 * M * sizeof(T), kind, stream));
       HIPCHK(hipMemcpyAsync(d_midx, idx, (size_t)M * sizeof(int), kind, stream));
+      sh_ident = -1;
     }
     int m = 0, m_pad = 0;
     int rc = build_innovation(M, plane, true, &m, &m_pad);
@@ -770,6 +771,7 @@ struct Filter : FilterBase {
     for (int k = 0; k < M; ++k)
       if (idx[k] < 0 || idx[k] >= N) FAIL(EKF_ERR_ARG, "feature index out of range");
     if (M > 0) HIPCHK(hipMemcpyAsync(d_midx, idx, (size_t)M * sizeof(int), hipMemcpyHostToDevice, stream));
+    sh_ident = -1;
     int m = 0, m_pad = 0;
     int rc = build_innovation(M, plane, false, &m, &m_pad);
     if (rc) return rc;
@@ -880,7 +882,7 @@ struct Filter : FilterBase {
   }
   // ---- multi-GPU row-panel sharding ------------------------------------------------
   int sh_rank = 0, sh_world = 1, sh_f0 = 0, sh_f1 = 0, sh_r0 = 0, sh_r1 = 0, sh_p0 = 0, sh_prows = 0;
-  int sh_m = 0, sh_m_pad = 0, sh_plane = 0, sh_stage = 0;
+  int sh_m = 0, sh_m_pad = 0, sh_plane = 0, sh_stage = 0, sh_ident = -1;
 
   int shard_configure(int rank, int world) override {
     if (world < 1 || rank < 0 || rank >= world) FAIL(EKF_ERR_ARG, "bad rank / world");
@@ -943,10 +945,13 @@ struct Filter : FilterBase {
     if (sh_stage != 1) FAIL(EKF_ERR_STATE, "ekf_shard_innovation follows ekf_shard_predict (+ gather of h / H)");
     if (M != N) FAIL(EKF_ERR_UNSUPPORTED, "sharded update measures every feature (M = N) in round 1");
     HIPCHK(hipMemcpyAsync(d_z, dz, (size_t)2 * M * sizeof(T), hipMemcpyDeviceToDevice, stream));
-    std::vector<int> ident(M);
-    for (int i = 0; i < M; ++i) ident[i] = i;
-    HIPCHK(hipMemcpyAsync(d_midx, ident.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice, stream));
-    HIPCHK(hipStreamSynchronize(stream));
+    if (sh_ident != M) {                                   // identity measured list, uploaded once
+      std::vector<int> ident(M);
+      for (int i = 0; i < M; ++i) ident[i] = i;
+      HIPCHK(hipMemcpyAsync(d_midx, ident.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+      sh_ident = M;
+    }
     const int nb = NB();
     const int m = 2 * M + (plane ? 3 : 0);
     const int m_pad = round_up(m, nb);
