@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-propagate-pass", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--pipeline", type=int, default=1, help="EKF_OPT_PIPELINE (overlap chain with solve/downdate pieces)")
+    ap.add_argument("--pipeline", type=int, default=0, help="EKF_OPT_PIPELINE (overlap chain with solve/downdate pieces)")
     return ap.parse_args()
 
 
@@ -165,7 +165,8 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
     roofline = None
     if syrk_cnt:
         t_k = syrk_ms / syrk_cnt * 1e-3
-        flop = float(n) * n * m                      # symmetric-half rank-m downdate
+        pieces = max(1, round(syrk_cnt / args.steps))  # > 1 only with --pipeline 1 (column groups of V)
+        flop = float(n) * n * m / pieces              # symmetric-half rank-m downdate
         ach = flop / t_k / 1e12
         roofline = {"kernel": "downdate_syrk (k_gemm_nt_mfma, f32 MFMA 32x32x2)", "bound": "mfma",
                     "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
