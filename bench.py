@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-propagate-pass", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--pipeline", type=int, default=0, help="EKF_OPT_PIPELINE (overlap chain with solve/downdate pieces)")
+    ap.add_argument("--pipeline", type=int, default=-1, help="EKF_OPT_PIPELINE (overlap chain with solve/downdate pieces)")
     return ap.parse_args()
 
 
@@ -163,6 +163,7 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
     m = 2 * n_feat
     syrk_ms, syrk_cnt = prof.get("downdate_syrk", (0.0, 0))
     roofline = None
+    pieces = 1
     if syrk_cnt:
         t_k = syrk_ms / syrk_cnt * 1e-3
         pieces = max(1, round(syrk_cnt / args.steps))  # > 1 only with --pipeline 1 (column groups of V)
@@ -174,6 +175,12 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
                     "avg_launch_ms": round(t_k * 1e3, 4), "launches": syrk_cnt,
                     "algorithmic_flop_per_launch": flop}
 
+    # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside bench.py)
+    pmc_path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    pmc = json.load(open(pmc_path))["kernels"] if (n_feat == 1000 and os.path.exists(pmc_path)) else {}
+    if roofline and "k_gemm_mfma<2, false>" in pmc and pieces == 1:
+        roofline["traffic"] = pmc["k_gemm_mfma<2, false>"]["hbm_bytes_per_launch"]
+        roofline["traffic_source"] = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2)"
     result = {
         "metric": "EKF updates/sec at N features (state dim 14+6N)",
         "value": round(args.steps / elapsed, 2), "unit": "updates/s",
@@ -209,7 +216,8 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
             gbs = nbytes / t_k / 1e9
             result["p_propagate"] = {"kernel": "k_propagate_streaming", "bound": "hbm",
                                      "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                     "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                                     "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                     "traffic": pmc.get("k_propagate_streaming<float>", {}).get("hbm_bytes_per_launch"),
                                      "avg_launch_ms": round(t_k * 1e3, 4),
                                      "algorithmic_bytes_per_launch": nbytes,
                                      "updates_per_s_with_streaming_propagate": round(args.steps / (t1 - t0), 2)}

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -146,14 +147,14 @@ struct Filter : FilterBase {
   int opt_streaming = 0, opt_mfma = 1, opt_profile = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  hipStream_t stream_b = nullptr;                       // overlaps solve / downdate pieces with the chain
-  hipEvent_t ev_chain[8] = {}, ev_b = nullptr;
-  int opt_pipeline = 0;
+  hipStream_t stream_b = nullptr, stream_c = nullptr;   // solve pieces / downdate pieces, overlapped with the chain
+  hipEvent_t ev_chain[8] = {}, ev_solve[8] = {}, ev_b = nullptr, ev_c = nullptr;
+  int opt_pipeline = -1;                                 // -1 auto: on when the chain has >= 8 block steps
   int* d_tilemap = nullptr;                             // work lists: [lower-tri super-tiles | solve heavy-first]
   int tilemap_nt = 0, tilemap_ntc = 0, tri_count = 0, solve_off = 0;
   int* d_counters = nullptr;                            // one work-queue head per queued launch of an update
   int counter_next = 0;
-  int num_cus = 256;
+  int num_cus = 256, reserved_cus = 32;
   // profiling
   struct Pending { int kid; hipEvent_t a, b; };
   std::vector<Pending> pending;
@@ -175,8 +176,11 @@ struct Filter : FilterBase {
     for (void* p : ptrs) if (p) hipFree(p);
     if (own_stream && stream) hipStreamDestroy(stream);
     if (stream_b) hipStreamDestroy(stream_b);
+    if (stream_c) hipStreamDestroy(stream_c);
     for (auto e : ev_chain) if (e) hipEventDestroy(e);
+    for (auto e : ev_solve) if (e) hipEventDestroy(e);
     if (ev_b) hipEventDestroy(ev_b);
+    if (ev_c) hipEventDestroy(ev_c);
   }
 
   // ---- profiling helpers ---------------------------------------------------------------
@@ -207,6 +211,7 @@ struct Filter : FilterBase {
     if (pending.empty()) return;
     hipStreamSynchronize(stream);
     hipStreamSynchronize(stream_b);
+    hipStreamSynchronize(stream_c);
     for (auto& p : pending) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { prof_ms[p.kid] += ms; prof_cnt[p.kid] += 1; }
@@ -240,11 +245,12 @@ struct Filter : FilterBase {
       int lo = 0, hi = 0;
       HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
       HIPCHK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi));   // the serial chain goes first
-      HIPCHK(hipStreamCreateWithPriority(&stream_b, hipStreamNonBlocking, lo));
     }
     own_stream = true;
     for (auto& e : ev_chain) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : ev_solve) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ev_b, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ev_c, hipEventDisableTiming));
     const size_t sig = (size_t)n_pad * ld;
     HIPCHK(hipMalloc(&d_S[0], sig * sizeof(T)));
     HIPCHK(hipMalloc(&d_S[1], sig * sizeof(T)));
@@ -286,6 +292,16 @@ struct Filter : FilterBase {
       HIPCHK(hipGetDeviceProperties(&prop, device));
       num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    {
+      // second stream for the pipelined solve / downdate pieces: kept off `reserved_cus` CUs so that
+      // the serial chain on the main stream always finds a free CU (a chain workgroup sharing its SIMDs
+      // with MFMA-saturating tile-GEMM waves runs ~4x slower: tools/coresidency.hip)
+      reserved_cus = std::min(32, num_cus / 4);
+      std::vector<uint32_t> mask((num_cus + 31) / 32, 0xffffffffu);
+      for (int i = 0; i < reserved_cus; ++i) mask[i / 32] &= ~(1u << (i % 32));
+      HIPCHK(hipExtStreamCreateWithCUMask(&stream_b, (uint32_t)mask.size(), mask.data()));
+      HIPCHK(hipExtStreamCreateWithCUMask(&stream_c, (uint32_t)mask.size(), mask.data()));
+    }
     // mu0 / Sigma0 (vR.cpp:163-180, 211-216)
     std::vector<T> mu0(camera_dim, T(0));
     mu0[3] = T(0.0); mu0[4] = T(0.0); mu0[5] = T(-0.707106781); mu0[6] = T(0.707106781);
@@ -305,10 +321,7 @@ struct Filter : FilterBase {
     // the diagonal-block kernel needs > 64 KiB of LDS
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_diag<T, 64>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, diag_lds(64)));
-    if constexpr (kIsF32) {
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_diag<T, 128>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, diag_lds(128)));
-    }
+    // (f32, NB = 128 uses k_chol_diag_packed: 66 KiB of static LDS)
     return EKF_OK;
   }
   static int diag_lds(int nb) { return 2 * nb * (nb + 1) * (int)sizeof(T); }
@@ -354,7 +367,7 @@ struct Filter : FilterBase {
       case EKF_OPT_PROPAGATE_STREAMING: opt_streaming = v ? 1 : 0; return EKF_OK;
       case EKF_OPT_USE_MFMA: opt_mfma = v ? 1 : 0; return EKF_OK;
       case EKF_OPT_PROFILE: resolve_profile(); opt_profile = v; return EKF_OK;
-      case EKF_OPT_PIPELINE: opt_pipeline = v ? 1 : 0; return EKF_OK;
+      case EKF_OPT_PIPELINE: opt_pipeline = (v < 0) ? -1 : (v ? 1 : 0); return EKF_OK;
       default: FAIL(EKF_ERR_ARG, "unknown option");
     }
   }
@@ -573,7 +586,10 @@ struct Filter : FilterBase {
       g.tile_map = tile_list;
       g.ntiles = ntiles;
       g.counter = d_counters + counter_next++;
-      grid = dim3(std::min(ntiles, 2 * num_cus), 1);
+      // persistent grid: two workgroups per CU the stream may use
+      const bool side = (st == stream_b || st == stream_c);
+      const int wgs = 2 * (side ? (num_cus - reserved_cus) : num_cus);
+      grid = dim3(std::min(ntiles, wgs), 1);
     }
     if constexpr (kIsF32) {
       if (opt_mfma) {
@@ -602,6 +618,7 @@ struct Filter : FilterBase {
       for (int i = 0; i < ntr; ++i) { tm.push_back(i); tm.push_back(j); }
     HIPCHK(hipStreamSynchronize(stream));
     HIPCHK(hipStreamSynchronize(stream_b));
+    HIPCHK(hipStreamSynchronize(stream_c));
     if (d_tilemap) HIPCHK(hipFree(d_tilemap));
     d_tilemap = nullptr;
     HIPCHK(hipMalloc(&d_tilemap, tm.size() * sizeof(int)));
@@ -682,7 +699,8 @@ struct Filter : FilterBase {
     //   solve piece g     V[:, g] = [W; nu^T] Z[:, g]        (K stops at the diagonal)
     //   downdate piece g  Sigma  -= V[:, g] V[:, g]^T
     const int nsteps = m_pad / nb;
-    const int ngroups = opt_pipeline ? std::min(4, nsteps) : 1;
+    const bool pipe = (opt_pipeline < 0) ? (nsteps >= 8) : (opt_pipeline != 0);
+    const int ngroups = pipe ? std::min(4, nsteps) : 1;
     const int tile = (kIsF32 && opt_mfma) ? 128 : 64;
     const int ntr = (npad_live + nb) / tile, ntc = m_pad / tile;
     rc = ensure_tilemap(npad_live / tile, ntr, ntc);
@@ -690,8 +708,14 @@ struct Filter : FilterBase {
     HIPCHK(hipMemsetAsync(d_counters, 0, 64 * sizeof(int), stream));
     counter_next = 0;
     int step = 0;
+    bool b_inflight = false;
     for (int gi = 0; gi < ngroups; ++gi) {
-      const int step_end = (int)((long long)nsteps * (gi + 1) / ngroups);
+      // uneven column groups: the last one has nothing to hide behind, so it is the smallest
+      static const int kGroupEnd16[4] = {4, 8, 12, 16};
+      int step_end = (ngroups == 4) ? (nsteps * kGroupEnd16[gi] + 15) / 16 : (int)((long long)nsteps * (gi + 1) / ngroups);
+      step_end = std::min(nsteps, std::max(step_end, step));
+      if (gi + 1 == ngroups) step_end = nsteps;
+      if (step_end == step) continue;                      // empty group (few steps)
       const int col_begin = step * nb;
       for (; step < step_end; ++step) {
         const int j = step * nb;
@@ -701,7 +725,7 @@ struct Filter : FilterBase {
           Scope sc(this, KID_CHOL_DIAG);
           if (nb == 128) {
             if constexpr (kIsF32)
-              k_chol_diag<T, 128><<<1, 512, diag_lds(128), stream>>>(Ajj, ldy, Dj, d_status);
+              k_chol_diag_packed<><<<1, 512, 0, stream>>>(Ajj, ldy, Dj, d_status);
           } else {
             k_chol_diag<T, 64><<<1, 512, diag_lds(64), stream>>>(Ajj, ldy, Dj, d_status);
           }
@@ -721,27 +745,37 @@ struct Filter : FilterBase {
       }
       const int col_end = step * nb;
       const int width = col_end - col_begin;
-      hipStream_t sb = opt_pipeline ? stream_b : stream;
-      if (opt_pipeline) {
+      // the last group has nothing left to overlap with: it runs on the main stream, on every CU
+      const bool overlap = pipe && step < nsteps;
+      hipStream_t ss = overlap ? stream_b : stream;       // solve pieces
+      hipStream_t sd = overlap ? stream_b : stream;       // downdate pieces follow their solve piece
+      if (!overlap && b_inflight) {                  // earlier pieces must be done before Sigma is touched again
+        HIPCHK(hipEventRecord(ev_b, stream_b));
+        HIPCHK(hipStreamWaitEvent(stream, ev_b, 0));
+        b_inflight = false;
+      }
+      if (overlap) {
+        b_inflight = true;
         HIPCHK(hipEventRecord(ev_chain[gi], stream));
         HIPCHK(hipStreamWaitEvent(stream_b, ev_chain[gi], 0));
       }
       {
-        Scope sc(this, KID_SOLVE, sb);                    // column tiles [col_begin, col_end) of V, heaviest first
+        Scope sc(this, KID_SOLVE, ss);                    // column tiles [col_begin, col_end) of V, heaviest first
         const int c0 = col_begin / tile, c1 = col_end / tile;
         const int* list = d_tilemap + solve_off + 2 * (ntc - c1) * ntr;
         gemm<ROLE_SOLVE, true>(d_W, ldy, Z, ldy, d_V, ldy, npad_live + nb, width, m_pad, T(1), T(0), 0, 0, 0, 1, 0,
-                               sb, list, (c1 - c0) * ntr);
+                               ss, list, (c1 - c0) * ntr);
       }
       {
-        Scope sc(this, KID_DOWNDATE, sb);                 // Sigma -= V_g V_g^T (lower tiles + mirror)
+        Scope sc(this, KID_DOWNDATE, sd);                 // Sigma -= V_g V_g^T (lower tiles + mirror)
         gemm<ROLE_DOWNDATE, false>(d_V + col_begin, ldy, d_V + col_begin, ldy, S(), ld, npad_live, npad_live, width,
-                                   T(-1), T(1), 2, 0, 0, 0, 0, sb, d_tilemap, tri_count);
+                                   T(-1), T(1), 2, 0, 0, 0, 0, sd, d_tilemap, tri_count);
       }
     }
-    if (opt_pipeline) {
+    if (b_inflight) {
       HIPCHK(hipEventRecord(ev_b, stream_b));
       HIPCHK(hipStreamWaitEvent(stream, ev_b, 0));
+      b_inflight = false;
     }
     const T* V = d_V;
     const T* yv = d_V + (size_t)npad_live * ldy;
@@ -1000,7 +1034,7 @@ struct Filter : FilterBase {
       T* Dj = d_Dinv + (size_t)step * nb * nb;
       { Scope sc(this, KID_CHOL_DIAG);
         if (nb == 128) {
-          if constexpr (kIsF32) k_chol_diag<T, 128><<<1, 512, diag_lds(128), stream>>>(Ajj, ldy, Dj, d_status);
+          if constexpr (kIsF32) k_chol_diag_packed<><<<1, 512, 0, stream>>>(Ajj, ldy, Dj, d_status);
         } else {
           k_chol_diag<T, 64><<<1, 512, diag_lds(64), stream>>>(Ajj, ldy, Dj, d_status);
         } }

@@ -287,6 +287,7 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(GemmArgs g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
+  if (ROLE == ROLE_PANEL || ROLE == ROLE_TRAILING) __builtin_amdgcn_s_setprio(2);   // part of the serial chain
   int bi, bj, iter = 0;
   while (gemm_next_tile(g, &s_tile, iter, bi, bj)) {
   const int grow0 = g.row_off + bi * TS, gcol0 = g.col_off + bj * TS;
@@ -575,6 +576,156 @@ k_chol_diag(T* __restrict__ Aglob, int ld, T* __restrict__ Dinv, int* __restrict
     Aglob[(size_t)i * ld + j] = (j <= i) ? a[i * LDA + j] : T(0);
     // bottom block holds Z = L^-T (upper): Linv[i][j] = Z[j][i]
     Dinv[(size_t)i * NB + j] = (j <= i) ? a[(NB + j) * LDA + i] : T(0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// f32 diagonal block, packed: ONE 128x129 LDS image (66 KiB, so the kernel can share a CU with
+// two tile-GEMM workgroups) holds L in the lower triangle and Z = L^-T in the strict upper
+// triangle; diag(Z) = 1/diag(L) is implied.  Inner blocking 16, 8 waves:
+//   (1) wave 0: 16x16 factor (v_rsq + v_readlane broadcasts) and its inverse X16, both in
+//       registers; writes L16 (lower), Z16 = X16^T (strict upper), 1/diag, X16;
+//   (2) 7 row blocks (rows below the block + Z rows of earlier blocks): P = Y X16^T, one
+//       16x16x16 product (4 v_mfma_f32_16x16x4_f32) per wave;
+//   (3) rank-16 update: lower tiles of the rows below, and Z tiles right of the block (the Z rows
+//       of the CURRENT block read their operand through a mask: 0 below, 1/diag on, Z16 above
+//       the diagonal).
+// ---------------------------------------------------------------------------------------
+template <int MASK = 7>
+__global__ void __launch_bounds__(512)
+k_chol_diag_packed(float* __restrict__ Aglob, int ld, float* __restrict__ Dinv, int* __restrict__ status) {
+  constexpr int NB = 128, LDA = NB + 1, NT = 512, NBLK = NB / 16;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __shared__ float a[NB * LDA];
+  __shared__ float x16[16 * 17];
+  __shared__ float rinv[16];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  __builtin_amdgcn_s_setprio(3);    // serial chain: win issue arbitration against co-resident tile-GEMM waves
+  {
+    // 4096 float4 of the block, 8 per lane, all loads in flight before the first LDS write
+    f4 v[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int q = tid + NT * p;                  // float4 index: row q / 32, columns 4 (q % 32) ..
+      v[p] = *reinterpret_cast<const f4*>(Aglob + (size_t)(q >> 5) * ld + 4 * (q & 31));
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int q = tid + NT * p;
+      const int i = q >> 5, j0 = 4 * (q & 31);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[i * LDA + j0 + e] = (j0 + e <= i) ? v[p][e] : 0.f;
+    }
+  }
+  __syncthreads();
+  for (int b = 0; b < NBLK; ++b) {
+    const int K0 = b * 16;
+    if ((MASK & 1) && wave == 0) {
+      const int i = lr;
+      float r[16], inv[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) r[j] = (j <= i) ? a[(K0 + i) * LDA + K0 + j] : 0.f;
+      bool bad = false;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const float pk = lane_bcast(r[k], k);
+        if (!(pk > 0.f)) bad = true;
+        inv[k] = __frsqrt_rn(pk > 0.f ? pk : 1.f);
+        const float lik = r[k] * inv[k];             // row k: pk * rsqrt(pk) = sqrt(pk)
+        r[k] = lik;
+#pragma unroll
+        for (int j = k + 1; j < 16; ++j) r[j] -= lik * lane_bcast(lik, j);
+      }
+      if (bad && lane == 0) status[0] = 1;
+      // X = L16^-1, lane c holds column c: x[i] = X[i][c]
+      float x[16];
+#pragma unroll
+      for (int ii = 0; ii < 16; ++ii) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < ii; ++k) acc += lane_bcast(r[k], ii) * x[k];
+        x[ii] = (ii == i) ? inv[ii] : -inv[ii] * acc;
+        if (ii < i) x[ii] = 0.f;
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          if (j <= i) a[(K0 + i) * LDA + K0 + j] = r[j];        // L16
+          else a[(K0 + i) * LDA + K0 + j] = x[j];               // Z16[i][j] = X[j][i]
+          x16[j * 17 + i] = x[j];                               // X16[j][i]
+        }
+        rinv[i] = inv[i];
+      }
+    }
+    __syncthreads();
+    const int nbelow = NBLK - 1 - b;                 // row blocks below the diagonal block
+    // (2) panel: row blocks {below} + {Z rows of earlier blocks}: NBLK - 1 of them
+    if ((MASK & 2) && wave < NBLK - 1) {
+      const int prow0 = (wave < nbelow) ? (K0 + 16 + wave * 16) : ((wave - nbelow) * 16);
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const float av = a[(prow0 + lr) * LDA + K0 + 4 * s4 + lq];
+        const float bv = x16[lr * 17 + 4 * s4 + lq];                   // B[k][col] = X16[col][k]
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[(prow0 + 4 * lq + e) * LDA + K0 + lr] = acc[e];
+    }
+    __syncthreads();
+    // (3) trailing update
+    if (MASK & 4) {
+      const int ntri = nbelow * (nbelow + 1) / 2;    // lower tiles of the rows below
+      const int nz = (b + 1) * nbelow;               // Z tiles: row blocks 0..b, column blocks b+1..
+      for (int t = wave; t < ntri + nz; t += NT / 64) {
+        int prow0, c0;
+        bool masked = false;
+        if (t < ntri) {
+          int rb = 0, rem = t;
+          while (rem > rb) { rem -= rb + 1; ++rb; }  // t -> (rb, cb = rem), cb <= rb
+          prow0 = K0 + 16 + rb * 16;
+          c0 = K0 + 16 + rem * 16;
+        } else {
+          const int u = t - ntri;
+          const int tb = u / nbelow, cb = u % nbelow;
+          prow0 = tb * 16;
+          c0 = K0 + 16 + cb * 16;
+          masked = (tb == b);
+        }
+        f4 acc;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = a[(prow0 + 4 * lq + e) * LDA + c0 + lr];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int k = 4 * s4 + lq;
+          float av = a[(prow0 + lr) * LDA + K0 + k];
+          if (masked) av = (k > lr) ? av : ((k == lr) ? rinv[lr] : 0.f);
+          const float bv = a[(c0 + lr) * LDA + K0 + k];
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(-av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[(prow0 + 4 * lq + e) * LDA + c0 + lr] = acc[e];
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int q = tid + NT * p;
+    const int i = q >> 5, j0 = 4 * (q & 31);
+    f4 lo, di;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = j0 + e;
+      const float l = a[i * LDA + j];
+      lo[e] = (j <= i) ? l : 0.f;
+      // Linv[i][j] = Z[j][i] (j < i: strict upper storage), 1 / L[i][i] on the diagonal
+      di[e] = (j < i) ? a[j * LDA + i] : ((j == i) ? 1.f / l : 0.f);
+    }
+    *reinterpret_cast<f4*>(Aglob + (size_t)i * ld + j0) = lo;
+    *reinterpret_cast<f4*>(Dinv + (size_t)i * NB + j0) = di;
   }
 }
 

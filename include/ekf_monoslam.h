@@ -71,7 +71,8 @@ enum ekf_option {
   /* profiling level: 0 off, 1 HIP events around the dominant kernels, 2 around every kernel. */
   EKF_OPT_PROFILE = 2,
   /* 1: the solve / downdate contractions are cut into column groups and overlapped with the
-   * serial Cholesky chain on a second stream; 0 (default): one stream, one launch each. */
+   * serial Cholesky chain on a second, CU-masked stream; 0: one stream, one launch each;
+   * -1 (default): on when the chain has at least 8 block steps (m >= 1024). */
   EKF_OPT_PIPELINE = 3
 };
 
