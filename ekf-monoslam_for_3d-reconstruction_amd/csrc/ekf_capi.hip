@@ -78,6 +78,8 @@ struct FilterBase {
   virtual int profile_reset() = 0;
   virtual void* dev_mu() = 0;
   virtual void* dev_sigma(int*) = 0;
+  virtual int search_ellipses(int, int*) = 0;
+  virtual int ransac(const void*, const int*, int, double, int*, unsigned char*, int*) = 0;
   virtual int shard_configure(int, int) = 0;
   virtual int shard_view(ekf_shard_view*) = 0;
   virtual int shard_predict(const void*, const void*, int) = 0;
@@ -172,7 +174,7 @@ struct Filter : FilterBase {
     for (auto e : pool) hipEventDestroy(e);
     void* ptrs[] = {d_pos, d_coding, d_mu[0], d_mu[1], d_S[0], d_S[1], d_scr, d_h, d_Hc, d_Hf, d_Sd,
                     d_flags, d_cflag, d_Jy, d_Yxyz, d_map_src, d_map_conv, d_Y, d_W, d_V, d_Dinv, d_z, d_midx,
-                    d_status, d_tmp, d_K, d_tilemap, d_counters};
+                    d_status, d_tmp, d_K, d_tilemap, d_counters, d_ibuf, d_rmask};
     for (void* p : ptrs) if (p) hipFree(p);
     if (own_stream && stream) hipStreamDestroy(stream);
     if (stream_b) hipStreamDestroy(stream_b);
@@ -914,6 +916,63 @@ struct Filter : FilterBase {
     if (c) for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) c[b * 3 + a] = o[3 + a * 3 + b];
     return EKF_OK;
   }
+  // ---- f2 / f1: search ellipses and 1-point RANSAC hypotheses -------------------------------------
+  int* d_ibuf = nullptr;                 // 3 N ints (ellipses) / M ints (counts)
+  unsigned char* d_rmask = nullptr;      // M x M inlier mask
+  size_t rmask_bytes = 0;
+
+  int search_ellipses(int sigma_size, int* out) override {
+    HIPCHK(hipSetDevice(device));
+    if (!have_meas) FAIL(EKF_ERR_STATE, "ekf_get_search_ellipses needs ekf_predict / ekf_measure first");
+    if (N == 0) return EKF_OK;
+    if (!d_ibuf) HIPCHK(hipMalloc(&d_ibuf, (size_t)std::max(capN, 1) * 3 * sizeof(int)));
+    k_search_ellipses<T><<<(N + 127) / 128, 128, 0, stream>>>(d_Sd, N, sigma_size, d_ibuf);
+    HIPCHK(hipMemcpyAsync(out, d_ibuf, (size_t)N * 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return EKF_OK;
+  }
+
+  int ransac(const void* z, const int* idx, int M, double thr, int* counts, unsigned char* inl, int* best) override {
+    HIPCHK(hipSetDevice(device));
+    if (M <= 0 || M > N || !z || !idx) FAIL(EKF_ERR_ARG, "bad measured set");
+    if (!have_meas) FAIL(EKF_ERR_STATE, "ekf_ransac_1point needs ekf_predict / ekf_measure first");
+    for (int k = 0; k < M; ++k)
+      if (idx[k] < 0 || idx[k] >= N) FAIL(EKF_ERR_ARG, "feature index out of range");
+    HIPCHK(hipMemcpyAsync(d_z, z, (size_t)2 * M * sizeof(T), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(d_midx, idx, (size_t)M * sizeof(int), hipMemcpyHostToDevice, stream));
+    sh_ident = -1;
+    int m = 0, m_pad = 0;
+    int rc = build_innovation(M, 0, false, &m, &m_pad);       // W = Sigma H^T for the listed features
+    if (rc) return rc;
+    have_update = false;
+    if (!d_ibuf) HIPCHK(hipMalloc(&d_ibuf, (size_t)std::max(capN, 1) * 3 * sizeof(int)));
+    if ((size_t)M * M > rmask_bytes) {
+      if (d_rmask) HIPCHK(hipFree(d_rmask));
+      d_rmask = nullptr;
+      HIPCHK(hipMalloc(&d_rmask, (size_t)M * M));
+      rmask_bytes = (size_t)M * M;
+    }
+    {
+      Scope sc(this, KID_MISC);
+      dim3 grid((M + 127) / 128, M);
+      k_ransac_eval<T><<<grid, 128, 0, stream>>>(mu(), d_W, ldy, d_Sd, d_h, d_z, d_pos, d_coding, d_midx, M, cam,
+                                                T(thr), d_rmask);
+      k_ransac_count<<<(M + 127) / 128, 128, 0, stream>>>(d_rmask, M, d_ibuf);
+    }
+    std::vector<int> cnt(M);
+    HIPCHK(hipMemcpyAsync(cnt.data(), d_ibuf, (size_t)M * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    int b = 0;
+    for (int k = 1; k < M; ++k) if (cnt[k] > cnt[b]) b = k;
+    if (counts) for (int k = 0; k < M; ++k) counts[k] = cnt[k];
+    if (best) *best = b;
+    if (inl) {
+      HIPCHK(hipMemcpy2DAsync(inl, 1, d_rmask + b, (size_t)M, 1, M, hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+    }
+    return EKF_OK;
+  }
+
   // ---- multi-GPU row-panel sharding ------------------------------------------------
   int sh_rank = 0, sh_world = 1, sh_f0 = 0, sh_f1 = 0, sh_r0 = 0, sh_r1 = 0, sh_p0 = 0, sh_prows = 0;
   int sh_m = 0, sh_m_pad = 0, sh_plane = 0, sh_stage = 0, sh_ident = -1;
@@ -1248,6 +1307,12 @@ const char* ekf_profile_kernel_name(int kid) { return (kid >= 0 && kid < ekf::KI
 int ekf_profile_read(ekf_filter* f, int kid, double* ms, long long* cnt) { IMPL_OR_ARG(f); return f->impl->profile_read(kid, ms, cnt); }
 int ekf_profile_reset(ekf_filter* f) { IMPL_OR_ARG(f); return f->impl->profile_reset(); }
 
+int ekf_get_search_ellipses(ekf_filter* f, int sigma_size, int* out) { IMPL_OR_ARG(f); if (!out) return EKF_ERR_ARG; return f->impl->search_ellipses(sigma_size, out); }
+int ekf_ransac_1point(ekf_filter* f, const void* z, const int* idx, int M, double thr, int* counts,
+                      unsigned char* inl, int* best) {
+  IMPL_OR_ARG(f);
+  return f->impl->ransac(z, idx, M, thr, counts, inl, best);
+}
 int ekf_shard_configure(ekf_filter* f, int rank, int world) { IMPL_OR_ARG(f); return f->impl->shard_configure(rank, world); }
 int ekf_shard_get_view(ekf_filter* f, ekf_shard_view* out) { IMPL_OR_ARG(f); return f->impl->shard_view(out); }
 int ekf_shard_predict(ekf_filter* f, const void* t, const void* r, int vc) { IMPL_OR_ARG(f); return f->impl->shard_predict(t, r, vc); }

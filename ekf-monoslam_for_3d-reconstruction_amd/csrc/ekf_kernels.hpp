@@ -558,6 +558,90 @@ __global__ void k_feature_xyz(const T* __restrict__ mu, const T* __restrict__ S,
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// f2: search-ellipse parameters of every feature from its 2x2 St block
+// (computeEllipsoidParameters, vR.cpp:1368-1382): semi-axes (int)(sigma_size*sqrt(eig)) (1 when the
+// eigenvalue is not positive), angle (int)(180/3.14*atan2(v1, v0)) of the eigenvector of the SMALLER
+// eigenvalue, taken with v0 >= 0 (an eigenvector's sign is arbitrary; the ellipse is the same).
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_search_ellipses(const T* __restrict__ Sd, int N, int sigma_size, int* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double a = double(Sd[4 * i]), b = 0.5 * (double(Sd[4 * i + 1]) + double(Sd[4 * i + 2])), c = double(Sd[4 * i + 3]);
+  const double mean = 0.5 * (a + c), dif = 0.5 * (a - c);
+  const double rad = sqrt(dif * dif + b * b);
+  const double e0 = mean - rad, e1 = mean + rad;
+  // eigenvector of e0: (b, e0 - a) or (e0 - c, b), whichever is better conditioned
+  double vx, vy;
+  if (fabs(e0 - a) > fabs(e0 - c)) { vx = b; vy = e0 - a; } else { vx = e0 - c; vy = b; }
+  if (vx == 0.0 && vy == 0.0) { vx = 1.0; vy = 0.0; }       // isotropic block
+  if (vx < 0.0 || (vx == 0.0 && vy < 0.0)) { vx = -vx; vy = -vy; }
+  out[3 * i + 0] = (e0 > 0.0) ? (int)(sigma_size * sqrt(e0)) : 1;
+  out[3 * i + 1] = (e1 > 0.0) ? (int)(sigma_size * sqrt(e1)) : 1;
+  out[3 * i + 2] = (int)(180.0 / 3.14 * atan2(vy, vx));
+}
+
+// ---------------------------------------------------------------------------------------
+// f1: 1-point RANSAC hypotheses (vR.cpp:986-1034), all of them at once.  Hypothesis k = measured
+// feature midx[k]: S_k = its 2x2 St block, K_k = Sigma H_k^T S_k^-1 = W[:, 2k:2k+2] S_k^-1,
+// mu_k = mu + K_k (z_k - h_k); every measured feature j is re-projected with mu_k (camera
+// quaternion re-normalised, :999) and is an inlier when |z_j - h_j(mu_k)| <= thr.
+// Lane = hypothesis k (coalesced along the columns of W), blockIdx.y = feature j.
+// Quirk kept: an XYZ feature is re-projected from the un-updated mu (:1016).
+// mask[j * M + k] = 1 / 0.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_ransac_eval(const T* __restrict__ mu, const T* __restrict__ W, int ldy,
+                              const T* __restrict__ Sd, const T* __restrict__ h, const T* __restrict__ z,
+                              const int* __restrict__ pos, const int* __restrict__ coding,
+                              const int* __restrict__ midx, int M, CamParams cam, T thr,
+                              unsigned char* __restrict__ mask) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y;
+  if (k >= M) return;
+  const int fk = midx[k], fj = midx[j];
+  // g = S_k^-1 nu_k
+  const T s00 = Sd[4 * fk], s01 = Sd[4 * fk + 1], s10 = Sd[4 * fk + 2], s11 = Sd[4 * fk + 3];
+  const T det = s00 * s11 - s01 * s10;
+  const T n0 = z[2 * k] - h[2 * fk], n1 = z[2 * k + 1] - h[2 * fk + 1];
+  const T g0 = (s11 * n0 - s01 * n1) / det, g1 = (-s10 * n0 + s00 * n1) / det;
+  T c[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) c[t] = mu[t] + W[(size_t)t * ldy + 2 * k] * g0 + W[(size_t)t * ldy + 2 * k + 1] * g1;
+  const T qn = t_sqrt(c[3] * c[3] + c[4] * c[4] + c[5] * c[5] + c[6] * c[6]);
+  const T qc[4] = {c[3] / qn, -c[4] / qn, -c[5] / qn, -c[6] / qn};
+  T R[9];
+  quat2rot(qc, R);
+  const int p = pos[fj];
+  T d[3];
+  if (coding[fj] == 0) {
+    T f[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+      f[t] = mu[p + t] + W[(size_t)(p + t) * ldy + 2 * k] * g0 + W[(size_t)(p + t) * ldy + 2 * k + 1] * g1;
+    const T st = t_sin(f[3]), ct = t_cos(f[3]), sp = t_sin(f[4]), cp = t_cos(f[4]);
+    d[0] = f[5] * (f[0] - c[0]) + st * cp;
+    d[1] = f[5] * (f[1] - c[1]) - sp;
+    d[2] = f[5] * (f[2] - c[2]) + ct * cp;
+  } else {
+    for (int t = 0; t < 3; ++t) d[t] = mu[p + t] - c[t];
+  }
+  T hC[3], hd[2], Jp[6];
+  mat3_vec(R, d, hC);
+  project_distort(cam, hC, hd, Jp);
+  const T e0 = z[2 * j] - hd[0], e1 = z[2 * j + 1] - hd[1];
+  mask[(size_t)j * M + k] = (t_sqrt(e0 * e0 + e1 * e1) <= thr) ? 1 : 0;
+}
+
+__global__ void k_ransac_count(const unsigned char* __restrict__ mask, int M, int* __restrict__ counts) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= M) return;
+  int c = 0;
+  for (int j = 0; j < M; ++j) c += mask[(size_t)j * M + k];
+  counts[k] = c;
+}
+
 template <typename T>
 __global__ void k_fill(T* __restrict__ p, size_t count, T v) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)

@@ -182,6 +182,26 @@ class VSlamFilter:
                                                         int(bool(plane_constraint)), self._ptr(out)))
         return out.T.copy()
 
+    def searchEllipses(self, sigma_size: Optional[int] = None):
+        """computeEllipsoidParameters (vR.cpp:1368-1382): (N,3) ints (a, b, theta_deg) per feature."""
+        N = self.numOfFeatures()
+        out = np.zeros((N, 3), np.int32)
+        ss = int(self._cfg.sigma_size if sigma_size is None else sigma_size)
+        self._check(self._lib.ekf_get_search_ellipses(self._h, ss, self._ptr(out)))
+        return out
+
+    def ransac1Point(self, z, indices, threshold: Optional[float] = None):
+        """All 1-point RANSAC hypotheses at once (vR.cpp:986-1034): (counts (M,), best k, inliers of best (M,))."""
+        z = np.ascontiguousarray(z, self.dtype).reshape(-1)
+        idx = np.ascontiguousarray(indices, np.int32)
+        thr = 2.0 * self._cfg.sigma_pixel if threshold is None else float(threshold)
+        counts = np.zeros(idx.size, np.int32)
+        inl = np.zeros(idx.size, np.uint8)
+        best = C.c_int()
+        self._check(self._lib.ekf_ransac_1point(self._h, self._ptr(z), self._ptr(idx), idx.size, thr,
+                                                self._ptr(counts), self._ptr(inl), C.byref(best)))
+        return counts, best.value, inl.astype(bool)
+
     def getGain(self):
         m = self._lib.ekf_last_measurement_rows(self._h)
         n = self.stateDim()

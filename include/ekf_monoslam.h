@@ -136,6 +136,21 @@ int ekf_update(ekf_filter* f, const void* z, const int* indices, int M, int plan
 int ekf_update_device(ekf_filter* f, const void* d_z, const int* d_indices, int M,
                       int plane_constraint);
 
+/* computeEllipsoidParameters (vR.cpp:1368-1382) for every feature, from the 2x2 St blocks of the last
+ * predict/measure: out holds 3 ints per feature (semi-axis of the smaller eigenvalue, of the larger one,
+ * angle in degrees of the minor-axis eigenvector with non-negative x component). */
+int ekf_get_search_ellipses(ekf_filter* f, int sigma_size, int* out);
+
+/* 1-point RANSAC hypothesis evaluation (vR.cpp:986-1034), every measured feature as a hypothesis, in
+ * one pass on the device: counts[k] = number of listed features within `threshold` pixels of their
+ * measurement after the single-feature update with feature indices[k] (the reference uses
+ * threshold = 2 * sigma_pixel, :968).  best = the hypothesis with most inliers (lowest k on ties;
+ * the reference keeps the flags of the LAST hypothesis it happened to draw, :1022 -- its stopping rule
+ * makes that one of the best; returning the best is the deterministic equivalent), inliers_of_best:
+ * 1 byte per listed feature.  Any output pointer may be NULL.  Needs ekf_predict / ekf_measure. */
+int ekf_ransac_1point(ekf_filter* f, const void* z, const int* indices, int M, double threshold,
+                      int* counts, unsigned char* inliers_of_best, int* best);
+
 /* Full St for a measured set (vR.cpp:598): out is m x m column-major, m = 2M (+3). */
 int ekf_innovation_covariance(ekf_filter* f, const int* indices, int M, int plane_constraint,
                               void* S_out);

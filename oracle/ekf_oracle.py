@@ -720,6 +720,51 @@ class DenseFilter:
         return y, J @ self.Sigma[pos:pos+6, pos:pos+6] @ J.T
 
 
+def ellipse_parameters(St, sigma_size):
+    """computeEllipsoidParameters, vR.cpp:1368-1382, for one 2x2 block: (a, b, theta_deg) ints.
+    SelfAdjointEigenSolver returns ascending eigenvalues; the sign of its eigenvectors is not
+    specified, the x >= 0 representative is taken here (same ellipse)."""
+    St = np.asarray(St, dtype=np.float64)
+    w, v = np.linalg.eigh(0.5 * (St + St.T))
+    vx, vy = v[0, 0], v[1, 0]
+    if vx < 0 or (vx == 0 and vy < 0):
+        vx, vy = -vx, -vy
+    a = int(sigma_size * math.sqrt(w[0])) if w[0] > 0 else 1
+    b = int(sigma_size * math.sqrt(w[1])) if w[1] > 0 else 1
+    return a, b, int(180 / 3.14 * math.atan2(vy, vx))
+
+
+def ransac_1point(filt, z, indices, threshold=None):
+    """The hypothesis loop of vR.cpp:986-1034 for EVERY listed feature as the hypothesis (the reference
+    draws them at random until its adaptive count runs out).  Returns (counts[M], mask[M(hyp), M(feature)])."""
+    T = filt.T
+    indices = list(indices)
+    M = len(indices)
+    z = np.asarray(z, T).reshape(M, 2)
+    thr = T(2 * filt.cfg.sigma_pixel if threshold is None else threshold)
+    mask = np.zeros((M, M), bool)
+    for k, fk in enumerate(indices):
+        ft = filt.features[fk]
+        H = filt.dense_H([fk])
+        S_i = H @ filt.Sigma @ H.T + T(filt.sigma_pixel_2) * np.eye(2, dtype=T)          # :994
+        K_i = filt.Sigma @ H.T @ np.linalg.inv(S_i)                                       # :995
+        mu_i = filt.mu + K_i @ (z[k] - ft.h)                                               # :996
+        r = mu_i[0:3]
+        q = mu_i[3:7] / T(np.sqrt(np.dot(mu_i[3:7], mu_i[3:7])))                            # :999
+        RotCW = quat2rot(quat_complement(q, T), T)
+        for j, fj in enumerate(indices):
+            g = filt.features[fj]
+            p = g.position_in_state
+            if g.coding == INV:
+                d, _ = inverse2xyz_projecting(mu_i[p:p+6], r, T, False)
+            else:
+                d = filt.mu[p:p+3] - r                                                      # mu, not mu_i (:1016)
+            hi, _ = filt.cam.project(RotCW @ d, False)
+            e = z[j] - hi
+            mask[k, j] = bool(T(np.sqrt(np.dot(e, e))) <= thr)                              # :1022
+    return mask.sum(axis=1).astype(np.int32), mask
+
+
 # --------------------------------------------------------------------------
 # structured filter: identical arithmetic, identity blocks exploited
 # --------------------------------------------------------------------------

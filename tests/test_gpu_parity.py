@@ -217,3 +217,42 @@ def test_nonpositive_rho_is_flagged_not_visible():     # vR.cpp:517-522
     assert rem[2] and not vis[2] and rem.sum() == 1
     assert ref.features[2].remove_flag and not ref.features[2].is_in_innovation
     assert relf(Hf[2], ref.features[2].Hf) < 1e-3 and np.allclose(h[2], ref.features[2].h, atol=1e-2)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_search_ellipses_match_oracle(dtype):          # vR.cpp:1368-1382
+    ref, g = make_pair(16, dtype)
+    ref.predict()
+    g.predict()
+    ell = g.searchEllipses(sigma_size=4)
+    for i, ft in enumerate(ref.features):
+        k = ft.position_in_z
+        a, b, th = o.ellipse_parameters(ref.St[k:k + 2, k:k + 2], 4)
+        assert abs(int(ell[i, 0]) - a) <= 1 and abs(int(ell[i, 1]) - b) <= 1
+        assert min(abs(int(ell[i, 2]) - th), 180 - abs(int(ell[i, 2]) - th)) <= 1
+        assert ell[i, 0] <= ell[i, 1]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_ransac_hypotheses_match_oracle(dtype):        # vR.cpp:986-1034
+    ref, g = make_pair(24, dtype)
+    ref.predict()
+    g.predict()
+    vis = ref.visible_indices()
+    z = o.synthetic_measurements(ref, vis, sigma=1.0).reshape(-1, 2)
+    z[3] += 40.0                                      # two gross mismatches
+    z[11] -= 35.0
+    counts_ref, mask_ref = o.ransac_1point(ref, z, vis)
+    counts, best, inl = g.ransac1Point(z, vis)
+    # borderline residuals (|e| within 1e-3 px of the threshold) may flip in fp32: allow one count
+    assert np.abs(counts - counts_ref).max() <= (0 if dtype == np.float64 else 1)
+    assert counts[best] == counts.max() and counts.max() >= len(vis) - 3
+    assert not inl[3] and not inl[11]
+    assert (inl != mask_ref[best]).sum() <= (0 if dtype == np.float64 else 1)
+    # the usual two-stage use: update with the low-innovation inliers only
+    sel = [vis[k] for k in range(len(vis)) if inl[k]]
+    zz = z[inl].reshape(-1)
+    ref.update(zz, sel)
+    g.update(zz, sel)
+    mu, S = gpu_state(g)
+    assert relf(S, ref.Sigma) < TOL[dtype]["S"]
