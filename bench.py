@@ -197,6 +197,28 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
     }
 
     if not args.no_propagate_pass:
+        # secondary workload: M = 32 measured features per frame, the reference's real
+        # operating point (conf_sim.cfg:24-25) -- the dense contractions shrink to rank 64 and the step
+        # becomes HBM-bound (W pass + rank-64 downdate stream Sigma)
+        m32 = min(32, n_feat)
+        flt3 = build_filter(pkg, cfg, n_feat, px0)
+        sel = torch.arange(m32, dtype=torch.int32, device=dev)
+        d_z32 = d_z[:, :2 * m32].contiguous()
+
+        def run32(first, count):
+            for f in range(first, first + count):
+                flt3.predict()
+                flt3.update_device(d_z32.data_ptr() + f * 2 * m32 * 4, sel.data_ptr(), m32, False)
+        run32(0, args.warmup)
+        flt3.synchronize()
+        t0 = time.perf_counter()
+        run32(args.warmup, args.steps)
+        flt3.synchronize()
+        t1 = time.perf_counter()
+        result["secondary_M32"] = {"measured_per_frame": m32, "value": round(args.steps / (t1 - t0), 2),
+                                   "unit": "updates/s", "ms_per_step": round(1e3 * (t1 - t0) / args.steps, 4)}
+        flt3.close()
+
         # second pass, same steps, streaming P-propagate: HBM GB/s of P <- F P F^T + Q
         flt2 = build_filter(pkg, cfg, n_feat, px0)
         flt2.set_option(0, 1)

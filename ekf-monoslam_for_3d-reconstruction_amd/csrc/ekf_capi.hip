@@ -154,6 +154,9 @@ struct Filter : FilterBase {
   int opt_pipeline = -1;                                 // -1 auto: on when the chain has >= 8 block steps
   int* d_tilemap = nullptr;                             // work lists: [lower-tri super-tiles | solve heavy-first]
   int tilemap_nt = 0, tilemap_ntc = 0, tri_count = 0, solve_off = 0;
+  const T* cur_z = nullptr;                              // measured pixels / list of the update in flight
+  const int* cur_midx = nullptr;
+  int w_zeroed_n = -1;                                   // n for which the pad rows of W were last cleared
   int* d_counters = nullptr;                            // one work-queue head per queued launch of an update
   int counter_next = 0;
   int num_cus = 256, reserved_cus = 32;
@@ -367,7 +370,7 @@ struct Filter : FilterBase {
   int set_option(int o, int v) override {
     switch (o) {
       case EKF_OPT_PROPAGATE_STREAMING: opt_streaming = v ? 1 : 0; return EKF_OK;
-      case EKF_OPT_USE_MFMA: opt_mfma = v ? 1 : 0; return EKF_OK;
+      case EKF_OPT_USE_MFMA: opt_mfma = v ? 1 : 0; w_zeroed_n = -1; return EKF_OK;   // tile size changes the pads
       case EKF_OPT_PROFILE: resolve_profile(); opt_profile = v; return EKF_OK;
       case EKF_OPT_PIPELINE: opt_pipeline = (v < 0) ? -1 : (v ? 1 : 0); return EKF_OK;
       default: FAIL(EKF_ERR_ARG, "unknown option");
@@ -631,33 +634,40 @@ struct Filter : FilterBase {
   }
 
   // W, S (and nu) for a measured set already resident in d_midx / d_z.
-  int build_innovation(int M, int plane, bool with_nu, int* m_out, int* m_pad_out) {
+  int build_innovation(int M, int plane, bool with_nu, int* m_out, int* m_pad_out, bool with_identity = false) {
     const int nb = NB();
     const int m = 2 * M + (plane ? 3 : 0);
     const int m_pad = round_up(m, nb);
     const int npad_live = round_up(n, nb);
     T* nu_row = d_W + (size_t)ldy * npad_live;
-    // pad rows of W (n..npad_live) and the nu block must be zero
-    if (npad_live > n)
-      HIPCHK(hipMemsetAsync(d_W + (size_t)n * ldy, 0, (size_t)(npad_live - n) * ldy * sizeof(T), stream));
-    HIPCHK(hipMemsetAsync(nu_row, 0, (size_t)nb * ldy * sizeof(T), stream));
+    // pad rows of W (n..npad_live) and the nu block must be zero; no kernel writes them except row
+    // npad_live (nu), so they are cleared only when the layout changed
+    if (w_zeroed_n != n) {
+      HIPCHK(hipMemsetAsync(d_W + (size_t)n * ldy, 0, (size_t)(npad_live - n + nb) * ldy * sizeof(T), stream));
+      w_zeroed_n = n;
+    }
+    const T* zp = cur_z ? cur_z : d_z;
+    const int* ip = cur_midx ? cur_midx : d_midx;
     if (with_nu) {
       Scope sc(this, KID_INNOVATION);
-      k_innovation<T><<<(m_pad + 255) / 256, 256, 0, stream>>>(d_z, d_h, d_midx, M, plane, mu(), nu_row, m_pad);
+      k_innovation<T><<<(std::max(m_pad, 64) + 255) / 256, 256, 0, stream>>>(zp, d_h, ip, M, plane, mu(), nu_row, m_pad,
+                                                                          d_counters);
+      counter_next = 0;
     }
     {
       Scope sc(this, KID_SIGMA_HT);
       constexpr int RB = 32;
       dim3 grid((m_pad / 2 + 255) / 256, (n + RB - 1) / RB);
-      k_sigma_ht<T, RB><<<grid, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane, d_W, ldy,
+      k_sigma_ht<T, RB><<<grid, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, ip, M, plane, d_W, ldy,
                                                 m_pad, 0, n);
     }
     {
       Scope sc(this, KID_INNOVATION_COV);
       constexpr int KB = 8;
       dim3 grid((m_pad + 255) / 256, std::max(1, (M + KB - 1) / KB));
-      k_innovation_cov<T, KB><<<grid, 256, 0, stream>>>(d_W, ldy, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane,
-                                                      T(sigma_pixel_2), T(0.00001), d_Y, m_pad, 0, M);
+      k_innovation_cov<T, KB><<<grid, 256, 0, stream>>>(d_W, ldy, d_Hc, d_Hf, d_pos, d_coding, ip, M, plane,
+                                                      T(sigma_pixel_2), T(0.00001), d_Y, m_pad, 0, M,
+                                                      with_identity ? d_Y + (size_t)m_pad * ldy : nullptr);
     }
     HIPCHK(hipGetLastError());
     *m_out = m;
@@ -676,24 +686,27 @@ struct Filter : FilterBase {
       for (int k = 0; k < M; ++k)
         if (idx[k] < 0 || idx[k] >= N) FAIL(EKF_ERR_ARG, "feature index out of range");
     }
+    cur_z = nullptr;
+    cur_midx = nullptr;
     if (M > 0) {
-      const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-      HIPCHK(hipMemcpyAsync(d_z, z, (size_t)2 * M * sizeof(T), kind, stream));
-      HIPCHK(hipMemcpyAsync(d_midx, idx, (size_t)M * sizeof(int), kind, stream));
-      sh_ident = -1;
+      if (on_device) {              // resident inputs are read in place (they must outlive the step)
+        cur_z = static_cast<const T*>(z);
+        cur_midx = idx;
+      } else {
+        HIPCHK(hipMemcpyAsync(d_z, z, (size_t)2 * M * sizeof(T), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(d_midx, idx, (size_t)M * sizeof(int), hipMemcpyHostToDevice, stream));
+        sh_ident = -1;
+      }
     }
     int m = 0, m_pad = 0;
-    int rc = build_innovation(M, plane, true, &m, &m_pad);
+    int rc = build_innovation(M, plane, true, &m, &m_pad, true);
+    cur_z = nullptr;
+    cur_midx = nullptr;
     if (rc) return rc;
     const int nb = NB();
     const int npad_live = round_up(n, nb);
     T* Y = d_Y;
     T* Z = d_Y + (size_t)m_pad * ldy;
-    {
-      Scope sc(this, KID_MISC);
-      dim3 grid((m_pad + 255) / 256, m_pad);
-      k_set_identity<T><<<grid, 256, 0, stream>>>(Z, ldy, m_pad);
-    }
     // tall blocked right-looking Cholesky: [S; I] -> [L; Z = L^-T].  At step j the rows that can
     // change are S rows below the diagonal block plus Z rows of block 0..j: always m_pad rows.
     // The chain is serial and small; the two large contractions are cut into column groups of
@@ -707,8 +720,7 @@ struct Filter : FilterBase {
     const int ntr = (npad_live + nb) / tile, ntc = m_pad / tile;
     rc = ensure_tilemap(npad_live / tile, ntr, ntc);
     if (rc) return rc;
-    HIPCHK(hipMemsetAsync(d_counters, 0, 64 * sizeof(int), stream));
-    counter_next = 0;
+
     int step = 0;
     bool b_inflight = false;
     for (int gi = 0; gi < ngroups; ++gi) {
@@ -1050,11 +1062,14 @@ struct Filter : FilterBase {
     const int m_pad = round_up(m, nb);
     const int npad_live = round_up(n, nb);
     T* nu_row = d_W + (size_t)ldy * npad_live;
-    if (npad_live > n)
-      HIPCHK(hipMemsetAsync(d_W + (size_t)n * ldy, 0, (size_t)(npad_live - n) * ldy * sizeof(T), stream));
-    HIPCHK(hipMemsetAsync(nu_row, 0, (size_t)nb * ldy * sizeof(T), stream));
+    if (w_zeroed_n != n) {
+      HIPCHK(hipMemsetAsync(d_W + (size_t)n * ldy, 0, (size_t)(npad_live - n + nb) * ldy * sizeof(T), stream));
+      w_zeroed_n = n;
+    }
     { Scope sc(this, KID_INNOVATION);
-      k_innovation<T><<<(m_pad + 255) / 256, 256, 0, stream>>>(d_z, d_h, d_midx, M, plane, mu(), nu_row, m_pad); }
+      k_innovation<T><<<(std::max(m_pad, 64) + 255) / 256, 256, 0, stream>>>(d_z, d_h, d_midx, M, plane, mu(), nu_row, m_pad,
+                                                                          d_counters);
+      counter_next = 0; }
     {
       Scope sc(this, KID_SIGMA_HT);
       constexpr int RB = 32;
@@ -1070,7 +1085,8 @@ struct Filter : FilterBase {
       constexpr int KB = 8;
       dim3 grid((m_pad + 255) / 256, std::max(1, (sh_f1 - sh_f0 + KB - 1) / KB));
       k_innovation_cov<T, KB><<<grid, 256, 0, stream>>>(d_W, ldy, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane,
-                                                      T(sigma_pixel_2), T(0.00001), d_Y, m_pad, sh_f0, sh_f1);
+                                                      T(sigma_pixel_2), T(0.00001), d_Y, m_pad, sh_f0, sh_f1,
+                                                      static_cast<T*>(nullptr));
     }
     HIPCHK(hipGetLastError());
     sh_m = m; sh_m_pad = m_pad; sh_plane = plane;

@@ -19,8 +19,10 @@ namespace ekf {
 // ---------------------------------------------------------------------------------------
 template <typename T>
 __global__ void k_innovation(const T* __restrict__ z, const T* __restrict__ h, const int* __restrict__ midx,
-                             int M, int plane, const T* __restrict__ mu, T* __restrict__ nu, int m_pad) {
+                             int M, int plane, const T* __restrict__ mu, T* __restrict__ nu, int m_pad,
+                             int* __restrict__ counters) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (counters && t < 64) counters[t] = 0;          // work-queue heads of this update's queued GEMMs
   if (t >= m_pad) return;
   T v = T(0);
   if (t < 2 * M) {
@@ -100,7 +102,7 @@ __global__ void k_innovation_cov(const T* __restrict__ W, int ldy,
                                  const T* __restrict__ Hc, const T* __restrict__ Hf,
                                  const int* __restrict__ pos, const int* __restrict__ coding,
                                  const int* __restrict__ midx, int M, int plane, T r_pix, T r_plane,
-                                 T* __restrict__ Sm, int m_pad, int k_begin, int k_end) {
+                                 T* __restrict__ Sm, int m_pad, int k_begin, int k_end, T* __restrict__ Zid) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= m_pad) return;
   const int m = 2 * M + (plane ? 3 : 0);
@@ -126,6 +128,10 @@ __global__ void k_innovation_cov(const T* __restrict__ W, int ldy,
     if (c >= m) { a0 = T(0); a1 = T(0); }
     Sm[(size_t)(2 * k) * ldy + c] = a0;
     Sm[(size_t)(2 * k + 1) * ldy + c] = a1;
+    if (Zid) {                          // identity block under S (rows m_pad + r), same sweep
+      Zid[(size_t)(2 * k) * ldy + c] = (c == 2 * k) ? T(1) : T(0);
+      Zid[(size_t)(2 * k + 1) * ldy + c] = (c == 2 * k + 1) ? T(1) : T(0);
+    }
   }
   if (blockIdx.y == gridDim.y - 1) {
     for (int r = 2 * M; r < m_pad; ++r) {
@@ -138,6 +144,7 @@ __global__ void k_innovation_cov(const T* __restrict__ W, int ldy,
         v = T(1);                       // identity padding keeps the padded factorisation regular
       }
       Sm[(size_t)r * ldy + c] = v;
+      if (Zid) Zid[(size_t)r * ldy + c] = (c == r) ? T(1) : T(0);
     }
   }
 }

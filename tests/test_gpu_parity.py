@@ -256,3 +256,38 @@ def test_ransac_hypotheses_match_oracle(dtype):        # vR.cpp:986-1034 (SURVEY
     g.update(zz, sel)
     mu, S = gpu_state(g)
     assert relf(S, ref.Sigma) < TOL[dtype]["S"]
+
+
+def test_plane_only_update_and_empty_map():
+    """M = 0 with the forsePlane pseudo-measurement (vR.cpp:1250-1281), and a filter with no features."""
+    ref, g = make_pair(6, np.float64)
+    ref.predict()
+    g.predict()
+    ref.update(np.zeros(0), [], plane=True)
+    g.update(np.zeros(0), [], plane_constraint=True)
+    mu, S = gpu_state(g)
+    assert relf(mu, ref.mu) < 1e-11 and relf(S, ref.Sigma) < 1e-9
+    # remove everything, keep filtering on the 14-state camera
+    g.removeFeatures(list(range(6)))
+    for i in range(5, -1, -1):
+        ref.remove_feature(i)
+    assert g.numOfFeatures() == 0 and g.stateDim() == 14
+    ref.predict()
+    g.predict()
+    g.update()
+    ref.update(np.zeros(0), [], plane=True)
+    g.update(np.zeros(0), [], plane_constraint=True)
+    mu, S = gpu_state(g)
+    assert relf(mu, ref.mu) < 1e-11 and relf(S, ref.Sigma) < 1e-9
+    assert g.addFeature((120.0, 100.0)) == 1 and g.stateDim() == 20
+
+
+def test_single_feature_update_f32():
+    ref, g = make_pair(30, np.float32)
+    ref.predict()
+    g.predict()
+    z = o.synthetic_measurements(ref, [17])
+    ref.update(z, [17])
+    g.update(z, [17])
+    mu, S = gpu_state(g)
+    assert relf(mu, ref.mu) < 1e-5 and relf(S, ref.Sigma) < 2e-4

@@ -13,18 +13,20 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 cfg = pkg.kinect_config()
 px0, z = synthetic.measurement_stream(cfg, N, steps + 3, sigma_px=bench.SIGMA_Z_PX)
 flt = bench.build_filter(pkg, cfg, N, px0)
-pipe = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+pipe = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+M = int(sys.argv[4]) if len(sys.argv) > 4 else N
 flt.set_option(3, pipe)
 dev = torch.device("cuda", 0)
 d_z = torch.from_numpy(z.reshape(z.shape[0], -1)).to(dev).contiguous()
-d_idx = torch.arange(N, dtype=torch.int32, device=dev)
-bpf = 2 * N * 4
-bench.run_steps(flt, d_z, d_idx, N, 0, 3, bpf)
+d_idx = torch.arange(M, dtype=torch.int32, device=dev)
+d_z = d_z[:, :2 * M].contiguous()
+bpf = 2 * M * 4
+bench.run_steps(flt, d_z, d_idx, M, 0, 3, bpf)
 flt.synchronize()
 flt.set_option(2, 2)
 flt.profile_reset()
 t0 = time.perf_counter()
-bench.run_steps(flt, d_z, d_idx, N, 3, steps, bpf)
+bench.run_steps(flt, d_z, d_idx, M, 3, steps, bpf)
 flt.synchronize()
 t1 = time.perf_counter()
 prof = flt.profile()
@@ -42,4 +44,4 @@ print("r est", mu[0:3], "true", r_true)
 print("q est", mu[3:7], "true", q_true)
 print("rho  min/med/max", mu[14:][5::6].min(), np.median(mu[14:][5::6]), mu[14:][5::6].max())
 zz = z[steps + 2]
-print("innovation rms px (next frame pred vs last z)", np.sqrt(np.mean((h - zz) ** 2)))
+print("innovation rms px (next frame pred vs last z)", np.sqrt(np.mean((h[:M] - zz[:M]) ** 2)))
