@@ -173,12 +173,15 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
                     "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F32_MFMA_TF, 4), "traffic": None,
                     "avg_launch_ms": round(t_k * 1e3, 4), "launches": syrk_cnt,
-                    "algorithmic_flop_per_launch": flop}
+                    "algorithmic_flop_per_launch": flop, "launches_per_step": pieces,
+                    "note": ("the downdate runs as %d column-group pieces per step on 224 of 256 CUs, overlapped with the "
+                             "serial Cholesky chain (EKF_OPT_PIPELINE); --pipeline 0 runs it as one launch" % pieces)
+                            if pieces > 1 else "one launch per step"}
 
     # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside bench.py)
     pmc_path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
     pmc = json.load(open(pmc_path))["kernels"] if (n_feat == 1000 and os.path.exists(pmc_path)) else {}
-    if roofline and "k_gemm_mfma<2, false>" in pmc and pieces == 1:
+    if roofline and "k_gemm_mfma<2, false>" in pmc:
         roofline["traffic"] = pmc["k_gemm_mfma<2, false>"]["hbm_bytes_per_launch"]
         roofline["traffic_source"] = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2)"
     result = {

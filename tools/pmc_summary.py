@@ -1,0 +1,40 @@
+"""Summarise the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) into profiles/<tag>_pmc_traffic.json.
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/<dir>/pmc_fetch -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/<dir>/pmc_write -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline
+    python tools/pmc_summary.py gpurun_out/<dir> profiles/r1_pmc_traffic.json
+
+Counters are KB per dispatch.  On gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads
+(MI355X_MICROARCH.md, HBM section), so the read side is doubled; WRITE_SIZE is exact."""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+
+
+def short(k):
+    return re.sub(r"\(.*", "", k).replace("void ekf::", "").replace("ekf::", "")
+
+
+out = {}
+for name, cn in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    f = sorted(glob.glob(f"{src}/pmc_{name}/*/*counter_collection.csv"))[-1]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        if k.startswith("k_"):
+            out.setdefault(k, {})[cn + "_KB_mean"] = sum(v) / len(v)
+            out[k]["dispatches_" + name] = len(v)
+for k, v in out.items():
+    v["hbm_bytes_per_launch"] = (2 * v.get("FETCH_SIZE_KB_mean", 0.0) + v.get("WRITE_SIZE_KB_mean", 0.0)) * 1024
+json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 5 --warmup 2 "
+                   "--no-cpu-baseline` (N=M=1000, fp32, default options: pipelined solve/downdate pieces); counters are KB per "
+                   "dispatch; read side doubled per MI355X_MICROARCH.md (FETCH_SIZE reports 1/2 of wide coalesced reads on gfx950)",
+           "kernels": out}, open(dst, "w"), indent=1)
+for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:10]:
+    print(f"{k:40s} {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB/launch")
