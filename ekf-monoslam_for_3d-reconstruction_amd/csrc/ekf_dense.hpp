@@ -598,14 +598,77 @@ k_chol_diag(T* __restrict__ Aglob, int ld, T* __restrict__ Dinv, int* __restrict
 //       of the CURRENT block read their operand through a mask: 0 below, 1/diag on, Z16 above
 //       the diagonal).
 // ---------------------------------------------------------------------------------------
+// One rank-16 tile update a[prow0.., c0..] -= P[prow0..][K0..] P[c0..][K0..]^T (4 MFMA 16x16x4).
+// `masked`: the operand rows are the Z rows of the CURRENT 16-block: 0 below, 1/diag on, Z16 above
+// the diagonal of the block.
+__device__ __forceinline__ void diag_tile_update(float* a, int LDA, int prow0, int c0, int K0, bool masked,
+                                                 const float* rinv, int lr, int lq) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 acc;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] = a[(prow0 + 4 * lq + e) * LDA + c0 + lr];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    const int k = 4 * s4 + lq;
+    float av = a[(prow0 + lr) * LDA + K0 + k];
+    if (masked) av = (k > lr) ? av : ((k == lr) ? rinv[lr] : 0.f);
+    const float bv = a[(c0 + lr) * LDA + K0 + k];
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(-av, bv, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) a[(prow0 + 4 * lq + e) * LDA + c0 + lr] = acc[e];
+}
+
+// 16x16 factor + inverse of the diagonal block at K0, in the registers of ONE wave (rows broadcast
+// with v_readlane): writes L16 (lower), Z16 = X16^T (strict upper), 1/diag and X16.
+// (A substitution panel that needs no X16 was measured slower: 1.7 us per step against 0.2 us for
+// the MFMA panel + 1.15 us for the inverse.)
+__device__ __forceinline__ void diag_factor16(float* a, int LDA, int K0, float* x16, float* rinv, int lane,
+                                              int* status) {
+  const int i = lane & 15;
+  float r[16], inv[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) r[j] = (j <= i) ? a[(K0 + i) * LDA + K0 + j] : 0.f;
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const float pk = lane_bcast(r[k], k);
+    if (!(pk > 0.f)) bad = true;
+    inv[k] = __frsqrt_rn(pk > 0.f ? pk : 1.f);
+    const float lik = r[k] * inv[k];             // row k: pk * rsqrt(pk) = sqrt(pk)
+    r[k] = lik;
+#pragma unroll
+    for (int j = k + 1; j < 16; ++j) r[j] -= lik * lane_bcast(lik, j);
+  }
+  if (bad && lane == 0) status[0] = 1;
+  float x[16];                                   // X = L16^-1, lane c holds column c: x[i] = X[i][c]
+#pragma unroll
+  for (int ii = 0; ii < 16; ++ii) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < ii; ++k) acc += lane_bcast(r[k], ii) * x[k];
+    x[ii] = (ii == i) ? inv[ii] : -inv[ii] * acc;
+    if (ii < i) x[ii] = 0.f;
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j <= i) a[(K0 + i) * LDA + K0 + j] = r[j];        // L16
+      else a[(K0 + i) * LDA + K0 + j] = x[j];               // Z16[i][j] = X[j][i]
+      x16[j * 17 + i] = x[j];                               // X16[j][i]
+    }
+    rinv[i] = inv[i];
+  }
+}
+
 template <int MASK = 7>
 __global__ void __launch_bounds__(512)
 k_chol_diag_packed(float* __restrict__ Aglob, int ld, float* __restrict__ Dinv, int* __restrict__ status) {
   constexpr int NB = 128, LDA = NB + 1, NT = 512, NBLK = NB / 16;
   typedef float f4 __attribute__((ext_vector_type(4)));
   __shared__ float a[NB * LDA];
-  __shared__ float x16[16 * 17];
-  __shared__ float rinv[16];
+  __shared__ float x16[2][16 * 17];              // double-buffered: block b+1 is factored while block b's
+  __shared__ float rinv[2][16];                  // trailing update is still being applied
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lq = lane >> 4;
@@ -627,93 +690,53 @@ k_chol_diag_packed(float* __restrict__ Aglob, int ld, float* __restrict__ Dinv, 
     }
   }
   __syncthreads();
+  if ((MASK & 1) && wave == 0) diag_factor16(a, LDA, 0, x16[0], rinv[0], lane, status);
+  __syncthreads();
   for (int b = 0; b < NBLK; ++b) {
     const int K0 = b * 16;
-    if ((MASK & 1) && wave == 0) {
-      const int i = lr;
-      float r[16], inv[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) r[j] = (j <= i) ? a[(K0 + i) * LDA + K0 + j] : 0.f;
-      bool bad = false;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const float pk = lane_bcast(r[k], k);
-        if (!(pk > 0.f)) bad = true;
-        inv[k] = __frsqrt_rn(pk > 0.f ? pk : 1.f);
-        const float lik = r[k] * inv[k];             // row k: pk * rsqrt(pk) = sqrt(pk)
-        r[k] = lik;
-#pragma unroll
-        for (int j = k + 1; j < 16; ++j) r[j] -= lik * lane_bcast(lik, j);
-      }
-      if (bad && lane == 0) status[0] = 1;
-      // X = L16^-1, lane c holds column c: x[i] = X[i][c]
-      float x[16];
-#pragma unroll
-      for (int ii = 0; ii < 16; ++ii) {
-        float acc = 0.f;
-#pragma unroll
-        for (int k = 0; k < ii; ++k) acc += lane_bcast(r[k], ii) * x[k];
-        x[ii] = (ii == i) ? inv[ii] : -inv[ii] * acc;
-        if (ii < i) x[ii] = 0.f;
-      }
-      if (lane < 16) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          if (j <= i) a[(K0 + i) * LDA + K0 + j] = r[j];        // L16
-          else a[(K0 + i) * LDA + K0 + j] = x[j];               // Z16[i][j] = X[j][i]
-          x16[j * 17 + i] = x[j];                               // X16[j][i]
-        }
-        rinv[i] = inv[i];
-      }
-    }
-    __syncthreads();
+    const float* xb = x16[b & 1];
+    const float* rb_inv = rinv[b & 1];
     const int nbelow = NBLK - 1 - b;                 // row blocks below the diagonal block
-    // (2) panel: row blocks {below} + {Z rows of earlier blocks}: NBLK - 1 of them
+    // (2) panel: row blocks {below} + {Z rows of earlier blocks}: NBLK - 1 of them, P = Y X16^T
     if ((MASK & 2) && wave < NBLK - 1) {
       const int prow0 = (wave < nbelow) ? (K0 + 16 + wave * 16) : ((wave - nbelow) * 16);
       f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
         const float av = a[(prow0 + lr) * LDA + K0 + 4 * s4 + lq];
-        const float bv = x16[lr * 17 + 4 * s4 + lq];                   // B[k][col] = X16[col][k]
+        const float bv = xb[lr * 17 + 4 * s4 + lq];                    // B[k][col] = X16[col][k]
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) a[(prow0 + 4 * lq + e) * LDA + K0 + lr] = acc[e];
     }
     __syncthreads();
-    // (3) trailing update
+    if (nbelow == 0) break;
+    // (3a) urgent tiles: block column b+1 (what the next 16x16 factor and the next panel read): the
+    // nbelow tiles below/at the diagonal + the Z tiles of row blocks 0..b: always NBLK tiles, one per wave
     if (MASK & 4) {
-      const int ntri = nbelow * (nbelow + 1) / 2;    // lower tiles of the rows below
-      const int nz = (b + 1) * nbelow;               // Z tiles: row blocks 0..b, column blocks b+1..
-      for (int t = wave; t < ntri + nz; t += NT / 64) {
-        int prow0, c0;
-        bool masked = false;
+      const bool top = wave < nbelow;
+      const int prow0 = top ? (K0 + 16 + wave * 16) : ((wave - nbelow) * 16);
+      diag_tile_update(a, LDA, prow0, K0 + 16, K0, !top && (wave - nbelow) == b, rb_inv, lr, lq);
+    }
+    __syncthreads();
+    // (1') wave 0 factors block b+1 while waves 1.. apply the rest of update b (block columns b+2..)
+    if (wave == 0) {
+      if (MASK & 1) diag_factor16(a, LDA, K0 + 16, x16[(b + 1) & 1], rinv[(b + 1) & 1], lane, status);
+    } else if (MASK & 4) {
+      const int nb1 = nbelow - 1;                  // remaining block columns
+      const int ntri = nb1 * (nb1 + 1) / 2;        // lower tiles (rb >= cb >= 1, relative to block b+1)
+      const int nz = (b + 1) * nb1;                // Z tiles: row blocks 0..b
+      for (int t = wave - 1; t < ntri + nz; t += NT / 64 - 1) {
         if (t < ntri) {
           int rb = 0, rem = t;
           while (rem > rb) { rem -= rb + 1; ++rb; }  // t -> (rb, cb = rem), cb <= rb
-          prow0 = K0 + 16 + rb * 16;
-          c0 = K0 + 16 + rem * 16;
+          diag_tile_update(a, LDA, K0 + 32 + rb * 16, K0 + 32 + rem * 16, K0, false, rb_inv, lr, lq);
         } else {
           const int u = t - ntri;
-          const int tb = u / nbelow, cb = u % nbelow;
-          prow0 = tb * 16;
-          c0 = K0 + 16 + cb * 16;
-          masked = (tb == b);
+          const int tb = u / nb1, cb = u % nb1;
+          diag_tile_update(a, LDA, tb * 16, K0 + 32 + cb * 16, K0, tb == b, rb_inv, lr, lq);
         }
-        f4 acc;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = a[(prow0 + 4 * lq + e) * LDA + c0 + lr];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          const int k = 4 * s4 + lq;
-          float av = a[(prow0 + lr) * LDA + K0 + k];
-          if (masked) av = (k > lr) ? av : ((k == lr) ? rinv[lr] : 0.f);
-          const float bv = a[(c0 + lr) * LDA + K0 + k];
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(-av, bv, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) a[(prow0 + 4 * lq + e) * LDA + c0 + lr] = acc[e];
       }
     }
     __syncthreads();

@@ -175,18 +175,30 @@ def test_camera_dim_13():
 
 
 def test_n200_stream_tracks_oracle():
-    """configs[1] shape (N=200, fp32): per-frame comparison with re-sync every 5 frames."""
+    """configs[1] shape (N=200, fp32, a slice of the 1000-frame stream): per-frame comparison with
+    re-sync every 10 frames, then 20 frames free-running; the bound is the fp32 oracle's own distance
+    from the fp64 oracle over the same frames (fp32 trajectories separate at rounding level per frame)."""
     ref, g = make_pair(200, np.float32)
+    ref64 = o.build_scenario(o.StructuredFilter, o.Config.kinect(), 200, np.float64)
     worst = 0.0
-    for k in range(10):
-        step(ref, g, seed=2000 + k)
+    for k in range(40):
+        ref.predict()
+        g.predict()
+        ref64.predict()
+        vis = ref.visible_indices()
+        z = o.synthetic_measurements(ref, vis, seed=2000 + k, sigma=0.5)
+        ref.update(z, vis)
+        g.update(z, vis)
+        ref64.update(z.astype(np.float64), vis)
         mu, S = gpu_state(g)
         worst = max(worst, relf(S, ref.Sigma))
-        assert relf(mu, ref.mu) < 5e-4
-        if k % 5 == 4:
+        assert relf(mu, ref.mu) < 5e-4, k
+        if k < 20 and k % 10 == 9:
             g.setFullState(ref.mu)
             g.setSigmaBlock(ref.Sigma)
-    assert worst < 2e-3
+    gap32_64 = relf(ref.Sigma, ref64.Sigma)
+    assert worst < max(2e-3, 5 * gap32_64)
+    assert relf(S, ref64.Sigma) < max(4e-3, 5 * gap32_64)
 
 
 def test_error_paths():
