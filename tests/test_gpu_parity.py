@@ -175,12 +175,12 @@ def test_camera_dim_13():
 
 
 def test_n200_stream_tracks_oracle():
-    """configs[1] shape (N=200, fp32, a slice of the 1000-frame stream): per-frame comparison with
-    re-sync every 10 frames, then 20 frames free-running; the bound is the fp32 oracle's own distance
-    from the fp64 oracle over the same frames (fp32 trajectories separate at rounding level per frame)."""
+    """configs[1] shape (N=200, fp32): 40 frames of the stream, free-running (no re-sync: injecting the
+    oracle's slightly asymmetric Sigma into the symmetric HIP filter only adds error).  Measured on the
+    MI355X: HIP-vs-fp32-oracle stays <= 1e-4 (Sigma) / 3e-6 (mu), and the HIP filter ends CLOSER to the
+    fp64 oracle than the fp32 oracle does (it keeps Sigma symmetric and never forms (I-KH)Sigma)."""
     ref, g = make_pair(200, np.float32)
     ref64 = o.build_scenario(o.StructuredFilter, o.Config.kinect(), 200, np.float64)
-    worst = 0.0
     for k in range(40):
         ref.predict()
         g.predict()
@@ -191,14 +191,10 @@ def test_n200_stream_tracks_oracle():
         g.update(z, vis)
         ref64.update(z.astype(np.float64), vis)
         mu, S = gpu_state(g)
-        worst = max(worst, relf(S, ref.Sigma))
-        assert relf(mu, ref.mu) < 5e-4, k
-        if k < 20 and k % 10 == 9:
-            g.setFullState(ref.mu)
-            g.setSigmaBlock(ref.Sigma)
-    gap32_64 = relf(ref.Sigma, ref64.Sigma)
-    assert worst < max(2e-3, 5 * gap32_64)
-    assert relf(S, ref64.Sigma) < max(4e-3, 5 * gap32_64)
+        assert relf(mu, ref.mu) < 2e-5, k
+        assert relf(S, ref.Sigma) < 3e-4, k
+    assert relf(mu, ref64.mu) < 2e-5 and relf(S, ref64.Sigma) < 3e-4
+    assert relf(S, ref64.Sigma) <= 2.0 * relf(ref.Sigma, ref64.Sigma)
 
 
 def test_error_paths():
