@@ -578,15 +578,16 @@ struct Filter : FilterBase {
 
   // ---- dense tile GEMM dispatch -----------------------------------------------------------
   // C[rows x cols] = beta C + alpha A op(B); rows, cols multiples of the tile.
-  template <int ROLE, bool BT>
+  // TM x TN: MFMA tile shape (64 or 128 each); the VALU path always uses 64 x 64.
+  template <int ROLE, bool BT, int TM = 128, int TN = 128>
   void gemm(const T* A, int lda, const T* B, int ldb, T* C, int ldc, int rows, int cols, int K, T alpha, T beta,
             int tri, int row_off, int col_off, int ktri, int ktile_off = 0, hipStream_t st = nullptr,
             const int* tile_list = nullptr, int ntiles = 0) {
     GemmArgs g{A, lda, B, ldb, C, ldc, K, double(alpha), double(beta), tri, row_off, col_off, ktri, ktile_off,
                nullptr, 0, nullptr};
     if (!st) st = stream;
-    const int ts = (kIsF32 && opt_mfma) ? 128 : 64;
-    dim3 grid(cols / ts, rows / ts);
+    const bool mf = kIsF32 && opt_mfma;
+    dim3 grid(cols / (mf ? TN : 64), rows / (mf ? TM : 64));
     if (tile_list && counter_next < 64) {
       g.tile_map = tile_list;
       g.ntiles = ntiles;
@@ -598,7 +599,7 @@ struct Filter : FilterBase {
     }
     if constexpr (kIsF32) {
       if (opt_mfma) {
-        k_gemm_mfma<ROLE, BT><<<grid, 256, 0, st>>>(g);
+        k_gemm_mfma<ROLE, BT, TM, TN><<<grid, 256, 0, st>>>(g);
         return;
       }
     }
@@ -748,13 +749,13 @@ struct Filter : FilterBase {
         {
           Scope sc(this, KID_CHOL_PANEL);                 // P = Y[r0:r0+m_pad, j:j+nb] * Linv_jj^T, in place
           T* P = Y + (size_t)r0 * ldy + j;
-          gemm<ROLE_PANEL, false>(P, ldy, Dj, nb, P, ldy, m_pad, nb, nb, T(1), T(0), 0, 0, 0, 0);
+          gemm<ROLE_PANEL, false, 64, 128>(P, ldy, Dj, nb, P, ldy, m_pad, nb, nb, T(1), T(0), 0, 0, 0, 0);
         }
         if (r0 < m_pad) {
           Scope sc(this, KID_CHOL_TRAILING);              // Y[r0:r0+m_pad, r0:m_pad] -= P P_S^T
           const T* P = Y + (size_t)r0 * ldy + j;
           T* C = Y + (size_t)r0 * ldy + r0;
-          gemm<ROLE_TRAILING, false>(P, ldy, P, ldy, C, ldy, m_pad, m_pad - r0, nb, T(-1), T(1), 1, r0, r0, 0);
+          gemm<ROLE_TRAILING, false, 64, 64>(P, ldy, P, ldy, C, ldy, m_pad, m_pad - r0, nb, T(-1), T(1), 1, r0, r0, 0);
         }
       }
       const int col_end = step * nb;
@@ -1116,12 +1117,12 @@ struct Filter : FilterBase {
       const int r0 = j + nb;
       { Scope sc(this, KID_CHOL_PANEL);
         T* P = Y + (size_t)r0 * ldy + j;
-        gemm<ROLE_PANEL, false>(P, ldy, Dj, nb, P, ldy, m_pad, nb, nb, T(1), T(0), 0, 0, 0, 0); }
+        gemm<ROLE_PANEL, false, 64, 128>(P, ldy, Dj, nb, P, ldy, m_pad, nb, nb, T(1), T(0), 0, 0, 0, 0); }
       if (r0 < m_pad) {
         Scope sc(this, KID_CHOL_TRAILING);
         const T* P = Y + (size_t)r0 * ldy + j;
         T* C = Y + (size_t)r0 * ldy + r0;
-        gemm<ROLE_TRAILING, false>(P, ldy, P, ldy, C, ldy, m_pad, m_pad - r0, nb, T(-1), T(1), 1, r0, r0, 0);
+        gemm<ROLE_TRAILING, false, 64, 64>(P, ldy, P, ldy, C, ldy, m_pad, m_pad - r0, nb, T(-1), T(1), 1, r0, r0, 0);
       }
     }
     {

@@ -279,45 +279,55 @@ __global__ void __launch_bounds__(256) k_gemm_valu(GemmArgs g) {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int ROLE, bool BT>
+template <int ROLE, bool BT, int TM = 128, int TN = 128>
 __global__ void __launch_bounds__(256) k_gemm_mfma(GemmArgs g) {
-  constexpr int TS = 128, BK = 32, NQ = BK / 4;
+  // TM x TN output tile (64 or 128 each), 4 waves as 2 x 2, each wave (TM/2) x (TN/2) = MI x NJ
+  // accumulators of 32x32.  The small shapes exist for the latency-bound launches (chain tiles, tail of
+  // the triangular solve): same flop, 2-4x the workgroups.
+  constexpr int BK = 32, NQ = BK / 4, MI = TM / 64, NJ = TN / 64, PA = TM / 32, PB = TN / 32;
+  static_assert((TM == 64 || TM == 128) && (TN == 64 || TN == 128), "tile shape");
   const float* A = static_cast<const float*>(g.A);
   const float* B = static_cast<const float*>(g.B);
   float* C = static_cast<float*>(g.C);
   const int lda = g.lda, ldb = g.ldb, ldc = g.ldc;
   const float alpha = float(g.alpha), beta = float(g.beta);
-  __shared__ f32x4 lds[2 * NQ * TS];          // A image then B image, 32 KiB
+  __shared__ f32x4 lds[NQ * (TM + TN)];       // A image then B image
   __shared__ int s_tile;
   f32x4* As = lds;
-  f32x4* Bs = lds + NQ * TS;
+  f32x4* Bs = lds + NQ * TM;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   if (ROLE == ROLE_PANEL || ROLE == ROLE_TRAILING) __builtin_amdgcn_s_setprio(2);   // part of the serial chain
   int bi, bj, iter = 0;
   while (gemm_next_tile(g, &s_tile, iter, bi, bj)) {
-  const int grow0 = g.row_off + bi * TS, gcol0 = g.col_off + bj * TS;
-  if (g.tri && grow0 + TS <= gcol0) continue;
-  const int K = g.ktri ? min(g.K, (bj + g.ktile_off + 1) * TS) : g.K;
-  // A staging: 1024 float4 per tile, 4 per lane; 8 consecutive lanes cover 128 B of a row
-  const float* Ag[4];
+  const int grow0 = g.row_off + bi * TM, gcol0 = g.col_off + bj * TN;
+  if (g.tri && grow0 + TM <= gcol0) continue;
+  const int K = g.ktri ? min(g.K, (bj + g.ktile_off + 1) * TN) : g.K;
+  // A staging: TM*8 float4 per tile, PA per lane; 8 consecutive lanes cover 128 B of a row
+  const float* Ag[PA];
   const float* Bg[4];
-  int aslot[4], bslot[4];
+  int aslot[PA], bslot[4];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  for (int p = 0; p < PA; ++p) {
     const int idx = tid + 256 * p;
     const int row = idx >> 3, q = idx & 7;
-    Ag[p] = A + (size_t)(bi * TS + row) * lda + q * 4;
-    aslot[p] = q * TS + (row ^ q);
+    Ag[p] = A + (size_t)(bi * TM + row) * lda + q * 4;
+    aslot[p] = q * TM + (row ^ q);
+  }
+  // NN mode: lane owns k-quad qk and column quad cq: rows 4qk+p (p < 4), 4 columns; TN = 64 uses lanes < 128
+  const int qk = tid / (TN / 4), cq = tid % (TN / 4);
+  const bool bt_active = !BT || qk < NQ;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
     if (!BT) {
-      Bg[p] = B + (size_t)(bj * TS + row) * ldb + q * 4;
-      bslot[p] = aslot[p];
+      const int idx = tid + 256 * p;
+      const int row = idx >> 3, q = idx & 7;
+      Bg[p] = (p < PB) ? B + (size_t)(bj * TN + row) * ldb + q * 4 : B;
+      bslot[p] = q * TN + (row ^ q);
     } else {
-      // lane owns k-quad qk = tid>>5 and column quad cq = tid&31: rows 4qk+p, 4 columns
-      const int qk = tid >> 5, cq = tid & 31;
-      Bg[p] = B + (size_t)(4 * qk + p) * ldb + bj * TS + 4 * cq;
-      bslot[p] = qk * TS + ((4 * cq + p) ^ qk);
+      Bg[p] = B + (size_t)(4 * (bt_active ? qk : 0) + p) * ldb + bj * TN + 4 * cq;
+      bslot[p] = qk * TN + ((4 * cq + p) ^ qk);
     }
   }
   const int h = lane >> 5, l31 = lane & 31;
@@ -325,45 +335,45 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(GemmArgs g) {
   // once, up front, under the first operand loads (alpha is never 0)
   // (the beta test is hoisted out of the element loop: a per-element "load or zero" select makes
   // hipcc branch around every load and wait for each one)
-  f32x16 acc[2][2];
+  f32x16 acc[MI][NJ];
   if (beta != 0.f) {
     const float cscale = beta / alpha;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float* Cp = C + (size_t)(bi * TS + wr * 64 + i * 32 + 4 * h) * ldc + bj * TS + wc * 64 + j * 32 + l31;
+      for (int j = 0; j < NJ; ++j) {
+        const float* Cp = C + (size_t)(bi * TM + wr * (TM / 2) + i * 32 + 4 * h) * ldc + bj * TN + wc * (TN / 2) + j * 32 + l31;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = Cp[(size_t)((e & 3) + 8 * (e >> 2)) * ldc];
       }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] *= cscale;
   } else {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   }
-  f32x4 ra[4], rb[4];
+  constexpr int PBL = BT ? 4 : PB;             // B float4 loads per lane
+  f32x4 ra[PA], rb[4];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    ra[p] = *reinterpret_cast<const f32x4*>(Ag[p]);
-    rb[p] = *reinterpret_cast<const f32x4*>(Bg[p]);
-  }
+  for (int p = 0; p < PA; ++p) ra[p] = *reinterpret_cast<const f32x4*>(Ag[p]);
+#pragma unroll
+  for (int p = 0; p < PBL; ++p) rb[p] = *reinterpret_cast<const f32x4*>(Bg[p]);
   for (int k0 = 0; k0 < K; k0 += BK) {
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < 4; ++p) As[aslot[p]] = ra[p];
+    for (int p = 0; p < PA; ++p) As[aslot[p]] = ra[p];
     if (!BT) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) Bs[bslot[p]] = rb[p];
-    } else {
+      for (int p = 0; p < PB; ++p) Bs[bslot[p]] = rb[p];
+    } else if (bt_active) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) {          // column 4cq+p gets (k0..k3) of that column
         f32x4 t = {rb[0][p], rb[1][p], rb[2][p], rb[3][p]};
@@ -373,40 +383,43 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(GemmArgs g) {
     __syncthreads();
     if (k0 + BK < K) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        ra[p] = *reinterpret_cast<const f32x4*>(Ag[p] + k0 + BK);
+      for (int p = 0; p < PA; ++p) ra[p] = *reinterpret_cast<const f32x4*>(Ag[p] + k0 + BK);
+#pragma unroll
+      for (int p = 0; p < PBL; ++p)
         rb[p] = BT ? *reinterpret_cast<const f32x4*>(Bg[p] + (size_t)(k0 + BK) * ldb)
                    : *reinterpret_cast<const f32x4*>(Bg[p] + k0 + BK);
-      }
     }
 #pragma unroll
     for (int s = 0; s < BK / 8; ++s) {
       const int q = 2 * s + h;
-      f32x4 fa[2], fb[2];
+      f32x4 fa[MI], fb[NJ];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int ar = wr * 64 + t * 32 + l31;
-        const int br = wc * 64 + t * 32 + l31;
-        fa[t] = As[q * TS + (ar ^ q)];
-        fb[t] = Bs[q * TS + (br ^ q)];
+      for (int t = 0; t < MI; ++t) {
+        const int ar = wr * (TM / 2) + t * 32 + l31;
+        fa[t] = As[q * TM + (ar ^ q)];
+      }
+#pragma unroll
+      for (int t = 0; t < NJ; ++t) {
+        const int br = wc * (TN / 2) + t * 32 + l31;
+        fb[t] = Bs[q * TN + (br ^ q)];
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < NJ; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     }
   }
   // epilogue: acc reg e of lane -> row (e&3) + 8*(e>>2) + 4*h, col l31 of the 32x32 tile
-  const bool mirror = (g.tri == 2) && (grow0 >= gcol0 + TS);
+  const bool mirror = (TM == TN) && (g.tri == 2) && (grow0 >= gcol0 + TM);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int rbase = bi * TS + wr * 64 + i * 32;
-      const int c = bj * TS + wc * 64 + j * 32 + l31;
+    for (int j = 0; j < NJ; ++j) {
+      const int rbase = bi * TM + wr * (TM / 2) + i * 32;
+      const int c = bj * TN + wc * (TN / 2) + j * 32 + l31;
       float v[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
