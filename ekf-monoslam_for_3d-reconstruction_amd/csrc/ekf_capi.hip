@@ -151,6 +151,7 @@ struct Filter : FilterBase {
   bool own_stream = false;
   hipStream_t stream_b = nullptr, stream_c = nullptr;   // solve pieces / downdate pieces, overlapped with the chain
   hipEvent_t ev_chain[8] = {}, ev_solve[8] = {}, ev_b = nullptr, ev_c = nullptr;
+  int opt_split16 = 8;
   int opt_pipeline = -1;                                 // -1 auto: on when the chain has >= 8 block steps
   int* d_tilemap = nullptr;                             // work lists: [lower-tri super-tiles | solve heavy-first]
   int tilemap_nt = 0, tilemap_ntc = 0, tri_count = 0, solve_off = 0;
@@ -372,7 +373,8 @@ struct Filter : FilterBase {
       case EKF_OPT_PROPAGATE_STREAMING: opt_streaming = v ? 1 : 0; return EKF_OK;
       case EKF_OPT_USE_MFMA: opt_mfma = v ? 1 : 0; w_zeroed_n = -1; return EKF_OK;   // tile size changes the pads
       case EKF_OPT_PROFILE: resolve_profile(); opt_profile = v; return EKF_OK;
-      case EKF_OPT_PIPELINE: opt_pipeline = (v < 0) ? -1 : (v ? 1 : 0); return EKF_OK;
+      case EKF_OPT_PIPELINE: opt_pipeline = (v < 0) ? -1 : v; return EKF_OK;
+      case 4: opt_split16 = std::max(1, std::min(15, v)); return EKF_OK;   // tuning knob: first group of a 2-group pipeline
       default: FAIL(EKF_ERR_ARG, "unknown option");
     }
   }
@@ -715,8 +717,10 @@ struct Filter : FilterBase {
     //   solve piece g     V[:, g] = [W; nu^T] Z[:, g]        (K stops at the diagonal)
     //   downdate piece g  Sigma  -= V[:, g] V[:, g]^T
     const int nsteps = m_pad / nb;
+    // opt_pipeline: -1 auto, 0/1 off/on (default group count), k >= 2: k column groups
     const bool pipe = (opt_pipeline < 0) ? (nsteps >= 8) : (opt_pipeline != 0);
-    const int ngroups = pipe ? std::min(4, nsteps) : 1;
+    const int want = (opt_pipeline >= 2) ? std::min(opt_pipeline, 8) : 2;     // 2 groups measured best (tools/sweep_groups.sh)
+    const int ngroups = pipe ? std::min(want, nsteps) : 1;
     const int tile = (kIsF32 && opt_mfma) ? 128 : 64;
     const int ntr = (npad_live + nb) / tile, ntc = m_pad / tile;
     rc = ensure_tilemap(npad_live / tile, ntr, ntc);
@@ -728,6 +732,7 @@ struct Filter : FilterBase {
       // uneven column groups: the last one has nothing to hide behind, so it is the smallest
       static const int kGroupEnd16[4] = {4, 8, 12, 16};
       int step_end = (ngroups == 4) ? (nsteps * kGroupEnd16[gi] + 15) / 16 : (int)((long long)nsteps * (gi + 1) / ngroups);
+      if (ngroups == 2 && gi == 0) step_end = (nsteps * opt_split16 + 15) / 16;   // first group: opt_split16 / 16 of the chain
       step_end = std::min(nsteps, std::max(step_end, step));
       if (gi + 1 == ngroups) step_end = nsteps;
       if (step_end == step) continue;                      // empty group (few steps)
