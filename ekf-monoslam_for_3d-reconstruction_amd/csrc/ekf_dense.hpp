@@ -291,10 +291,9 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(GemmArgs g) {
   float* C = static_cast<float*>(g.C);
   const int lda = g.lda, ldb = g.ldb, ldc = g.ldc;
   const float alpha = float(g.alpha), beta = float(g.beta);
-  __shared__ f32x4 lds[NQ * (TM + TN)];       // A image then B image
+  __shared__ f32x4 lds[2 * NQ * (TM + TN)];   // two stages of {A image, B image}: one barrier per K step
   __shared__ int s_tile;
-  f32x4* As = lds;
-  f32x4* Bs = lds + NQ * TM;
+  constexpr int STAGE = NQ * (TM + TN);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -362,12 +361,16 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(GemmArgs g) {
   }
   constexpr int PBL = BT ? 4 : PB;             // B float4 loads per lane
   f32x4 ra[PA], rb[4];
+  auto load_tile = [&](int k0) {
 #pragma unroll
-  for (int p = 0; p < PA; ++p) ra[p] = *reinterpret_cast<const f32x4*>(Ag[p]);
+    for (int p = 0; p < PA; ++p) ra[p] = *reinterpret_cast<const f32x4*>(Ag[p] + k0);
 #pragma unroll
-  for (int p = 0; p < PBL; ++p) rb[p] = *reinterpret_cast<const f32x4*>(Bg[p]);
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    __syncthreads();
+    for (int p = 0; p < PBL; ++p)
+      rb[p] = BT ? *reinterpret_cast<const f32x4*>(Bg[p] + (size_t)k0 * ldb) : *reinterpret_cast<const f32x4*>(Bg[p] + k0);
+  };
+  auto store_tile = [&](int stage) {
+    f32x4* As = lds + stage * STAGE;
+    f32x4* Bs = As + NQ * TM;
 #pragma unroll
     for (int p = 0; p < PA; ++p) As[aslot[p]] = ra[p];
     if (!BT) {
@@ -380,15 +383,22 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(GemmArgs g) {
         Bs[bslot[p]] = t;
       }
     }
-    __syncthreads();
+  };
+  // software pipeline: tile k computes from stage k&1 while tile k+1 is written to the other stage and
+  // tile k+2 is in flight from global memory; one barrier per K step
+  __syncthreads();                             // the previous tile of this workgroup is done with the LDS
+  load_tile(0);
+  store_tile(0);
+  if (BK < K) load_tile(BK);
+  __syncthreads();
+  int stage = 0;
+  for (int k0 = 0; k0 < K; k0 += BK, stage ^= 1) {
     if (k0 + BK < K) {
-#pragma unroll
-      for (int p = 0; p < PA; ++p) ra[p] = *reinterpret_cast<const f32x4*>(Ag[p] + k0 + BK);
-#pragma unroll
-      for (int p = 0; p < PBL; ++p)
-        rb[p] = BT ? *reinterpret_cast<const f32x4*>(Bg[p] + (size_t)(k0 + BK) * ldb)
-                   : *reinterpret_cast<const f32x4*>(Bg[p] + k0 + BK);
+      store_tile(stage ^ 1);
+      if (k0 + 2 * BK < K) load_tile(k0 + 2 * BK);
     }
+    const f32x4* As = lds + stage * STAGE;
+    const f32x4* Bs = As + NQ * TM;
 #pragma unroll
     for (int s = 0; s < BK / 8; ++s) {
       const int q = 2 * s + h;
@@ -411,6 +421,7 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(GemmArgs g) {
           for (int j = 0; j < NJ; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     }
+    __syncthreads();
   }
   // epilogue: acc reg e of lane -> row (e&3) + 8*(e>>2) + 4*h, col l31 of the 32x32 tile
   const bool mirror = (TM == TN) && (g.tri == 2) && (grow0 >= gcol0 + TM);
