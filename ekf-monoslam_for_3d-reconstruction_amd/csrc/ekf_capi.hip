@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -303,6 +304,7 @@ struct Filter : FilterBase {
       // the serial chain on the main stream always finds a free CU (a chain workgroup sharing its SIMDs
       // with MFMA-saturating tile-GEMM waves runs ~4x slower: tools/coresidency.hip)
       reserved_cus = std::min(32, num_cus / 4);
+      if (const char* e = getenv("EKF_RESERVED_CUS")) reserved_cus = std::max(1, std::min(num_cus / 2, atoi(e)));   // tuning knob
       std::vector<uint32_t> mask((num_cus + 31) / 32, 0xffffffffu);
       for (int i = 0; i < reserved_cus; ++i) mask[i / 32] &= ~(1u << (i % 32));
       HIPCHK(hipExtStreamCreateWithCUMask(&stream_b, (uint32_t)mask.size(), mask.data()));
