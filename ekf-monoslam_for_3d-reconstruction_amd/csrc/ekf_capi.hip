@@ -145,6 +145,7 @@ struct Filter : FilterBase {
   size_t K_elems = 0;
   int last_m = 0, last_m_pad = 0, last_n = 0;
   bool have_meas = false;
+  bool have_sd = false;                                  // 2x2 St blocks of the current h/H evaluated?
   bool have_update = false;
   // options
   int opt_streaming = 0, opt_mfma = 1, opt_profile = 0;
@@ -514,11 +515,11 @@ struct Filter : FilterBase {
     if (rc) return rc;
     if (N > 0) {
       Scope sc(this, KID_MEASURE);
-      k_measure<T><<<(N + 63) / 64, 64, 0, stream>>>(mu(), S(), ld, d_pos, d_coding, 0, N, cam, T(sigma_pixel_2), d_h,
-                                                    d_Hc, d_Hf, d_flags, d_Sd);
+      k_measure<T><<<(N + 63) / 64, 64, 0, stream>>>(mu(), d_pos, d_coding, 0, N, cam, d_h, d_Hc, d_Hf, d_flags);
     }
     HIPCHK(hipGetLastError());
     have_meas = true;
+    have_sd = false;
     return EKF_OK;
   }
 
@@ -558,6 +559,17 @@ struct Filter : FilterBase {
     return launch_measure();
   }
 
+  // 2x2 St blocks on demand (they need the propagated Sigma and the current H; nothing on the device
+  // consumes them except the ellipse / RANSAC kernels)
+  int ensure_sd() {
+    if (have_sd || N == 0) return EKF_OK;
+    k_measure_sd<T><<<(16 * N + 255) / 256, 256, 0, stream>>>(S(), ld, d_pos, d_coding, 0, N, T(sigma_pixel_2), d_Hc, d_Hf,
+                                                             d_Sd);
+    HIPCHK(hipGetLastError());
+    have_sd = true;
+    return EKF_OK;
+  }
+
   int get_predictions(void* h, unsigned char* vis, unsigned char* rem, void* s2, void* hc, void* hf) override {
     HIPCHK(hipSetDevice(device));
     if (!have_meas) FAIL(EKF_ERR_STATE, "no predictions: call ekf_predict / ekf_measure first");
@@ -566,7 +578,7 @@ struct Filter : FilterBase {
     std::vector<T> sd, vhc, vhf;
     if (h) HIPCHK(hipMemcpyAsync(h, d_h, (size_t)N * 2 * sizeof(T), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipMemcpyAsync(fl.data(), d_flags, N, hipMemcpyDeviceToHost, stream));
-    if (s2) { sd.resize((size_t)N * 4); HIPCHK(hipMemcpyAsync(sd.data(), d_Sd, sd.size() * sizeof(T), hipMemcpyDeviceToHost, stream)); }
+    if (s2) { int rcs = ensure_sd(); if (rcs) return rcs; sd.resize((size_t)N * 4); HIPCHK(hipMemcpyAsync(sd.data(), d_Sd, sd.size() * sizeof(T), hipMemcpyDeviceToHost, stream)); }
     if (hc) { vhc.resize((size_t)N * 14); HIPCHK(hipMemcpyAsync(vhc.data(), d_Hc, vhc.size() * sizeof(T), hipMemcpyDeviceToHost, stream)); }
     if (hf) { vhf.resize((size_t)N * 12); HIPCHK(hipMemcpyAsync(vhf.data(), d_Hf, vhf.size() * sizeof(T), hipMemcpyDeviceToHost, stream)); }
     HIPCHK(hipStreamSynchronize(stream));
@@ -659,20 +671,36 @@ struct Filter : FilterBase {
                                                                           d_counters);
       counter_next = 0;
     }
+    // small problems are latency-bound: fewer rows / features per workgroup so that the grid fills the chip
+    const bool small = (size_t)n * m_pad < ((size_t)1 << 22);
     {
       Scope sc(this, KID_SIGMA_HT);
-      constexpr int RB = 32;
-      dim3 grid((m_pad / 2 + 255) / 256, (n + RB - 1) / RB);
-      k_sigma_ht<T, RB><<<grid, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, ip, M, plane, d_W, ldy,
-                                                m_pad, 0, n);
+      if (small) {
+        constexpr int RB = 4;
+        dim3 grid((m_pad / 2 + 255) / 256, (n + RB - 1) / RB);
+        k_sigma_ht<T, RB><<<grid, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, ip, M, plane, d_W, ldy,
+                                                  m_pad, 0, n);
+      } else {
+        constexpr int RB = 32;
+        dim3 grid((m_pad / 2 + 255) / 256, (n + RB - 1) / RB);
+        k_sigma_ht<T, RB><<<grid, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, ip, M, plane, d_W, ldy,
+                                                  m_pad, 0, n);
+      }
     }
     {
       Scope sc(this, KID_INNOVATION_COV);
-      constexpr int KB = 8;
-      dim3 grid((m_pad + 255) / 256, std::max(1, (M + KB - 1) / KB));
-      k_innovation_cov<T, KB><<<grid, 256, 0, stream>>>(d_W, ldy, d_Hc, d_Hf, d_pos, d_coding, ip, M, plane,
-                                                      T(sigma_pixel_2), T(0.00001), d_Y, m_pad, 0, M,
-                                                      with_identity ? d_Y + (size_t)m_pad * ldy : nullptr);
+      T* zid = with_identity ? d_Y + (size_t)m_pad * ldy : nullptr;
+      if (small) {
+        constexpr int KB = 1;
+        dim3 grid((m_pad + 255) / 256, std::max(1, (M + KB - 1) / KB));
+        k_innovation_cov<T, KB><<<grid, 256, 0, stream>>>(d_W, ldy, d_Hc, d_Hf, d_pos, d_coding, ip, M, plane,
+                                                        T(sigma_pixel_2), T(0.00001), d_Y, m_pad, 0, M, zid);
+      } else {
+        constexpr int KB = 8;
+        dim3 grid((m_pad + 255) / 256, std::max(1, (M + KB - 1) / KB));
+        k_innovation_cov<T, KB><<<grid, 256, 0, stream>>>(d_W, ldy, d_Hc, d_Hf, d_pos, d_coding, ip, M, plane,
+                                                        T(sigma_pixel_2), T(0.00001), d_Y, m_pad, 0, M, zid);
+      }
     }
     HIPCHK(hipGetLastError());
     *m_out = m;
@@ -945,6 +973,7 @@ struct Filter : FilterBase {
     HIPCHK(hipSetDevice(device));
     if (!have_meas) FAIL(EKF_ERR_STATE, "ekf_get_search_ellipses needs ekf_predict / ekf_measure first");
     if (N == 0) return EKF_OK;
+    { int rcs = ensure_sd(); if (rcs) return rcs; }
     if (!d_ibuf) HIPCHK(hipMalloc(&d_ibuf, (size_t)std::max(capN, 1) * 3 * sizeof(int)));
     k_search_ellipses<T><<<(N + 127) / 128, 128, 0, stream>>>(d_Sd, N, sigma_size, d_ibuf);
     HIPCHK(hipMemcpyAsync(out, d_ibuf, (size_t)N * 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -962,6 +991,7 @@ struct Filter : FilterBase {
     HIPCHK(hipMemcpyAsync(d_midx, idx, (size_t)M * sizeof(int), hipMemcpyHostToDevice, stream));
     sh_ident = -1;
     int m = 0, m_pad = 0;
+    { int rcs = ensure_sd(); if (rcs) return rcs; }
     int rc = build_innovation(M, 0, false, &m, &m_pad);       // W = Sigma H^T for the listed features
     if (rc) return rc;
     have_update = false;
@@ -1044,8 +1074,8 @@ struct Filter : FilterBase {
     {
       Scope sc(this, KID_MEASURE);
       const int cnt = sh_f1 - sh_f0;
-      k_measure<T><<<(cnt + 63) / 64, 64, 0, stream>>>(mu(), S(), ld, d_pos, d_coding, sh_f0, sh_f1, cam,
-                                                        T(sigma_pixel_2), d_h, d_Hc, d_Hf, d_flags, d_Sd);
+      k_measure<T><<<(cnt + 63) / 64, 64, 0, stream>>>(mu(), d_pos, d_coding, sh_f0, sh_f1, cam, d_h, d_Hc, d_Hf,
+                                                        d_flags);
     }
     HIPCHK(hipGetLastError());
     have_update = false;

@@ -30,70 +30,87 @@ struct MotionArgs {
 // ---------------------------------------------------------------------------------------
 template <typename T>
 __global__ void k_predict_camera(T* __restrict__ mu, T* __restrict__ scr, MotionArgs a) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  T x[13];
-  for (int i = 0; i < 13; ++i) x[i] = mu[i];
+  // one workgroup of 64 lanes: lane 0 forms the two non-trivial blocks of Ft, all lanes fill Ft / Q
+  __shared__ T sF[169];
+  __shared__ T sx[13];
+  const int tid = threadIdx.x;
+  if (blockIdx.x != 0) return;
+  if (tid < 13) sx[tid] = mu[tid];
+  for (int i = tid; i < 169; i += blockDim.x) sF[i] = (i / 13 == i % 13) ? T(1) : T(0);
+  __syncthreads();
   const T dTt = T(a.dT);
-  T q[4] = {x[3], x[4], x[5], x[6]};
-  T wc[3] = {x[10] + T(a.r_ctl[0]), x[11] + T(a.r_ctl[1]), x[12] + T(a.r_ctl[2])};
-  T hv[3] = {dTt * wc[0], dTt * wc[1], dTt * wc[2]};
-  T h[4];
-  vec2quat(hv, h);
-  T Ft[169];
-  for (int i = 0; i < 169; ++i) Ft[i] = T(0);
-  for (int i = 0; i < 13; ++i) Ft[i * 13 + i] = T(1);
-  // Ft[3:7,3:7] = Upsilon-bar(h)
-  const T hb[16] = {h[0], -h[1], -h[2], -h[3],
-                    h[1],  h[0],  h[3], -h[2],
-                    h[2], -h[3],  h[0],  h[1],
-                    h[3],  h[2], -h[1],  h[0]};
-  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) Ft[(3 + r) * 13 + 3 + c] = hb[r * 4 + c];
-  // Ft[3:7,10:13] = Upsilon(q) * t2(w, dT); trigonometry in double like the reference (dT is double)
-  const T nw = t_sqrt(wc[0] * wc[0] + wc[1] * wc[1] + wc[2] * wc[2]);
-  const double ang = a.dT * double(nw) / 2.0;
-  const T s = T(sin(ang));
-  const T c = T(cos(ang));
-  const T sinc = (nw == T(0)) ? T(1) : T(2.0 * sin(ang) / (a.dT * double(nw)));
-  T n_w[3] = {T(0), T(0), T(0)};
-  if (nw > T(0)) { n_w[0] = wc[0] / nw; n_w[1] = wc[1] / nw; n_w[2] = wc[2] / nw; }
-  T t2[12];
-  const T a0 = T(-a.dT * 0.5 * double(s));
-  const T half = T(a.dT * 0.5);
-  for (int j = 0; j < 3; ++j) t2[j] = a0 * n_w[j];
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j)
-      t2[(1 + i) * 3 + j] = half * ((i == j ? sinc : T(0)) + (c - sinc) * n_w[i] * n_w[j]);
-  const T up[16] = {q[0], -q[1], -q[2], -q[3],
-                    q[1],  q[0], -q[3],  q[2],
-                    q[2],  q[3],  q[0], -q[1],
-                    q[3], -q[2],  q[1],  q[0]};
-  for (int r = 0; r < 4; ++r)
-    for (int j = 0; j < 3; ++j) {
-      T acc = T(0);
-      for (int k = 0; k < 4; ++k) acc += up[r * 4 + k] * t2[k * 3 + j];
-      Ft[(3 + r) * 13 + 10 + j] = acc;
-    }
-  for (int i = 0; i < 3; ++i) Ft[i * 13 + 7 + i] = dTt;
-  for (int i = 0; i < 169; ++i) scr[SCR_FT + i] = Ft[i];
-  // Q = Ft[:,7:13] diag(V / dT / dT) Ft[:,7:13]^T
-  T vs[6];
-  for (int k = 0; k < 6; ++k) vs[k] = T(a.vdiag[k]) / dTt / dTt;
-  for (int i = 0; i < 13; ++i)
-    for (int j = 0; j < 13; ++j) {
-      T acc = T(0);
-      for (int k = 0; k < 6; ++k) acc += Ft[i * 13 + 7 + k] * vs[k] * Ft[j * 13 + 7 + k];
-      scr[SCR_Q + i * 13 + j] = acc;
-    }
-  // Predict_State
-  T v[3] = {x[7] + T(a.t_ctl[0]), x[8] + T(a.t_ctl[1]), x[9] + T(a.t_ctl[2])};
-  T w[3] = {x[10] + T(a.r_ctl[0]), x[11] + T(a.r_ctl[1]), x[12] + T(a.r_ctl[2])};
-  T dq[4], qn[4];
-  T wv[3] = {dTt * w[0], dTt * w[1], dTt * w[2]};
-  vec2quat(wv, dq);
-  quat_mul(q, dq, qn);
-  for (int i = 0; i < 3; ++i) mu[i] = x[i] + dTt * v[i];
-  for (int i = 0; i < 4; ++i) mu[3 + i] = qn[i];
-  for (int i = 0; i < 3; ++i) { mu[7 + i] = v[i]; mu[10 + i] = w[i]; }
+  if (tid == 0) {
+    const T q[4] = {sx[3], sx[4], sx[5], sx[6]};
+    const T wc[3] = {sx[10] + T(a.r_ctl[0]), sx[11] + T(a.r_ctl[1]), sx[12] + T(a.r_ctl[2])};
+    const T hv[3] = {dTt * wc[0], dTt * wc[1], dTt * wc[2]};
+    T h[4];
+    vec2quat(hv, h);
+    // Ft[3:7,3:7] = Upsilon-bar(h)
+    const T hb[16] = {h[0], -h[1], -h[2], -h[3],
+                      h[1],  h[0],  h[3], -h[2],
+                      h[2], -h[3],  h[0],  h[1],
+                      h[3],  h[2], -h[1],  h[0]};
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) sF[(3 + r) * 13 + 3 + c] = hb[r * 4 + c];
+    // Ft[3:7,10:13] = Upsilon(q) * t2(w, dT); trigonometry in double like the reference (dT is double)
+    const T nw = t_sqrt(wc[0] * wc[0] + wc[1] * wc[1] + wc[2] * wc[2]);
+    const double ang = a.dT * double(nw) / 2.0;
+    const T s = T(sin(ang));
+    const T c = T(cos(ang));
+    const T sinc = (nw == T(0)) ? T(1) : T(2.0 * sin(ang) / (a.dT * double(nw)));
+    T n_w[3] = {T(0), T(0), T(0)};
+    if (nw > T(0)) { n_w[0] = wc[0] / nw; n_w[1] = wc[1] / nw; n_w[2] = wc[2] / nw; }
+    T t2[12];
+    const T a0 = T(-a.dT * 0.5 * double(s));
+    const T half = T(a.dT * 0.5);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) t2[j] = a0 * n_w[j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        t2[(1 + i) * 3 + j] = half * ((i == j ? sinc : T(0)) + (c - sinc) * n_w[i] * n_w[j]);
+    const T up[16] = {q[0], -q[1], -q[2], -q[3],
+                      q[1],  q[0], -q[3],  q[2],
+                      q[2],  q[3],  q[0], -q[1],
+                      q[3], -q[2],  q[1],  q[0]};
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        T acc = T(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc += up[r * 4 + k] * t2[k * 3 + j];
+        sF[(3 + r) * 13 + 10 + j] = acc;
+      }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) sF[i * 13 + 7 + i] = dTt;
+    // Predict_State
+    const T v[3] = {sx[7] + T(a.t_ctl[0]), sx[8] + T(a.t_ctl[1]), sx[9] + T(a.t_ctl[2])};
+    const T w[3] = {sx[10] + T(a.r_ctl[0]), sx[11] + T(a.r_ctl[1]), sx[12] + T(a.r_ctl[2])};
+    T dq[4], qn[4];
+    const T wv[3] = {dTt * w[0], dTt * w[1], dTt * w[2]};
+    vec2quat(wv, dq);
+    quat_mul(q, dq, qn);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) mu[i] = sx[i] + dTt * v[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mu[3 + i] = qn[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { mu[7 + i] = v[i]; mu[10 + i] = w[i]; }
+  }
+  __syncthreads();
+  // Ft and Q = Ft[:,7:13] diag(V / dT / dT) Ft[:,7:13]^T, one entry per lane-iteration
+  for (int e = tid; e < 169; e += blockDim.x) {
+    const int i = e / 13, j = e % 13;
+    scr[SCR_FT + e] = sF[e];
+    T acc = T(0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc += sF[i * 13 + 7 + k] * (T(a.vdiag[k]) / dTt / dTt) * sF[j * 13 + 7 + k];
+    scr[SCR_Q + e] = acc;
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -239,16 +256,15 @@ __global__ void k_propagate_streaming(const T* __restrict__ src, T* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------
-// a4 / a5 / a6: one lane per feature: h, compact H (2x7 + 2x6), flags, and the 2x2 diagonal
-// block of St.  flags bit0 = visible (vR.cpp:529), bit1 = rho <= 0 (vR.cpp:517-521).
+// a4 / a5 / a6: one lane per feature: h, compact H (2x7 + 2x6), flags.  flags bit0 = visible (vR.cpp:529), bit1 = rho <= 0 (vR.cpp:517-521).
 // Hc: [N][2][7], Hf: [N][2][6] row-major (XYZ features: last 3 columns zero).
 // ---------------------------------------------------------------------------------------
 template <typename T>
-__global__ void k_measure(const T* __restrict__ mu, const T* __restrict__ S, int ld,
+__global__ void k_measure(const T* __restrict__ mu,
                           const int* __restrict__ pos, const int* __restrict__ coding, int f_begin, int N,
-                          CamParams cam, T r_pix,
+                          CamParams cam,
                           T* __restrict__ h_out, T* __restrict__ Hc, T* __restrict__ Hf,
-                          unsigned char* __restrict__ flags, T* __restrict__ Sd) {
+                          unsigned char* __restrict__ flags) {
   const int i = f_begin + blockIdx.x * blockDim.x + threadIdx.x;   // features [f_begin, N)
   if (i >= N) return;
   const int p = pos[i];
@@ -315,29 +331,47 @@ __global__ void k_measure(const T* __restrict__ mu, const T* __restrict__ S, int
   for (int k = 0; k < 14; ++k) Hc[(size_t)i * 14 + k] = hc[k];
   for (int k = 0; k < 12; ++k) Hf[(size_t)i * 12 + k] = hf[k];
   flags[i] = fl;
-  // 2x2 block of St: Hrow P Hrow^T + r_pix I with P = Sigma[idx, idx], idx = [0..6, p..p+fs)
-  T t0[13], t1[13];                                  // (P Hrow^T) columns
-  for (int a = 0; a < 13; ++a) {
+}
+
+// 2x2 diagonal block of St per feature: Hrow P Hrow^T + r_pix I with P = Sigma[idx, idx],
+// idx = [0..6, p..p+fs).  Only host-facing consumers need it (the gate of Patch::findMatch, the search
+// ellipses, the RANSAC hypotheses), so it is evaluated on demand, 16 lanes per feature: lane a owns row
+// a of P (13 + 3 idle), and the 2x2 sums are reduced with shuffles.
+template <typename T>
+__global__ void k_measure_sd(const T* __restrict__ S, int ld, const int* __restrict__ pos,
+                             const int* __restrict__ coding, int f_begin, int N, T r_pix,
+                             const T* __restrict__ Hc, const T* __restrict__ Hf, T* __restrict__ Sd) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = f_begin + (gid >> 4);
+  const int a = gid & 15;
+  const bool live = i < N;
+  const int fi = live ? i : f_begin;
+  const int p = pos[fi];
+  const int fs = coding[fi] ? 3 : 6;
+  const T* hc = Hc + (size_t)fi * 14;
+  const T* hf = Hf + (size_t)fi * 12;
+  T acc0 = T(0), acc1 = T(0);
+  T h0 = T(0), h1 = T(0);                    // Hrow[0][a], Hrow[1][a]
+  if (live && a < 7 + fs) {
     const int ra = (a < 7) ? a : p + (a - 7);
-    T acc0 = T(0), acc1 = T(0);
-    if (a < 7 + fs) {
-      const T* row = S + (size_t)ra * ld;
-      for (int b = 0; b < 7; ++b) { const T v = row[b]; acc0 += v * hc[b]; acc1 += v * hc[7 + b]; }
-      for (int b = 0; b < fs; ++b) { const T v = row[p + b]; acc0 += v * hf[b]; acc1 += v * hf[6 + b]; }
-    }
-    t0[a] = acc0; t1[a] = acc1;
+    const T* row = S + (size_t)ra * ld;
+    for (int b = 0; b < 7; ++b) { const T v = row[b]; acc0 += v * hc[b]; acc1 += v * hc[7 + b]; }
+    for (int b = 0; b < fs; ++b) { const T v = row[p + b]; acc0 += v * hf[b]; acc1 += v * hf[6 + b]; }
+    h0 = (a < 7) ? hc[a] : hf[a - 7];
+    h1 = (a < 7) ? hc[7 + a] : hf[6 + a - 7];
   }
-  T s00 = T(0), s01 = T(0), s10 = T(0), s11 = T(0);
-  for (int a = 0; a < 7; ++a) {
-    s00 += hc[a] * t0[a]; s01 += hc[a] * t1[a]; s10 += hc[7 + a] * t0[a]; s11 += hc[7 + a] * t1[a];
+  T s00 = h0 * acc0, s01 = h0 * acc1, s10 = h1 * acc0, s11 = h1 * acc1;
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) {
+    s00 += __shfl_down(s00, off, 16); s01 += __shfl_down(s01, off, 16);
+    s10 += __shfl_down(s10, off, 16); s11 += __shfl_down(s11, off, 16);
   }
-  for (int a = 0; a < fs; ++a) {
-    s00 += hf[a] * t0[7 + a]; s01 += hf[a] * t1[7 + a]; s10 += hf[6 + a] * t0[7 + a]; s11 += hf[6 + a] * t1[7 + a];
+  if (live && a == 0) {
+    Sd[(size_t)i * 4 + 0] = s00 + r_pix;
+    Sd[(size_t)i * 4 + 1] = s01;
+    Sd[(size_t)i * 4 + 2] = s10;
+    Sd[(size_t)i * 4 + 3] = s11 + r_pix;
   }
-  Sd[(size_t)i * 4 + 0] = s00 + r_pix;
-  Sd[(size_t)i * 4 + 1] = s01;
-  Sd[(size_t)i * 4 + 2] = s10;
-  Sd[(size_t)i * 4 + 3] = s11 + r_pix;
 }
 
 // ---------------------------------------------------------------------------------------
