@@ -79,6 +79,7 @@ struct FilterBase {
   virtual int profile_reset() = 0;
   virtual void* dev_mu() = 0;
   virtual void* dev_sigma(int*) = 0;
+  virtual int export_points(void*, int) = 0;
   virtual int search_ellipses(int, int*) = 0;
   virtual int ransac(const void*, const int*, int, double, int*, unsigned char*, int*) = 0;
   virtual int shard_configure(int, int) = 0;
@@ -180,7 +181,7 @@ struct Filter : FilterBase {
     for (auto e : pool) hipEventDestroy(e);
     void* ptrs[] = {d_pos, d_coding, d_mu[0], d_mu[1], d_S[0], d_S[1], d_scr, d_h, d_Hc, d_Hf, d_Sd,
                     d_flags, d_cflag, d_Jy, d_Yxyz, d_map_src, d_map_conv, d_Y, d_W, d_V, d_Dinv, d_z, d_midx,
-                    d_status, d_tmp, d_K, d_tilemap, d_counters, d_ibuf, d_rmask};
+                    d_status, d_tmp, d_K, d_tilemap, d_counters, d_ibuf, d_rmask, d_pts};
     for (void* p : ptrs) if (p) hipFree(p);
     if (own_stream && stream) hipStreamDestroy(stream);
     if (stream_b) hipStreamDestroy(stream_b);
@@ -969,6 +970,24 @@ struct Filter : FilterBase {
   unsigned char* d_rmask = nullptr;      // M x M inlier mask
   size_t rmask_bytes = 0;
 
+  T* d_pts = nullptr;
+  int export_points(void* out, int convert) override {
+    HIPCHK(hipSetDevice(device));
+    if (N == 0) return EKF_OK;
+    int rc = sync_layout();
+    if (rc) return rc;
+    if (!d_pts) HIPCHK(hipMalloc(&d_pts, (size_t)std::max(capN, 1) * 12 * sizeof(T)));
+    T scale = T(1);
+    if (camera_dim == 14) {
+      HIPCHK(hipMemcpyAsync(&scale, mu() + 13, sizeof(T), hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+    }
+    k_export_points<T><<<(N + 63) / 64, 64, 0, stream>>>(mu(), S(), ld, d_pos, d_coding, N, scale, convert, d_pts);
+    HIPCHK(hipMemcpyAsync(out, d_pts, (size_t)N * 12 * sizeof(T), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return check_status();
+  }
+
   int search_ellipses(int sigma_size, int* out) override {
     HIPCHK(hipSetDevice(device));
     if (!have_meas) FAIL(EKF_ERR_STATE, "ekf_get_search_ellipses needs ekf_predict / ekf_measure first");
@@ -1361,6 +1380,7 @@ const char* ekf_profile_kernel_name(int kid) { return (kid >= 0 && kid < ekf::KI
 int ekf_profile_read(ekf_filter* f, int kid, double* ms, long long* cnt) { IMPL_OR_ARG(f); return f->impl->profile_read(kid, ms, cnt); }
 int ekf_profile_reset(ekf_filter* f) { IMPL_OR_ARG(f); return f->impl->profile_reset(); }
 
+int ekf_export_points(ekf_filter* f, void* out, int conv) { IMPL_OR_ARG(f); if (!out) return EKF_ERR_ARG; return f->impl->export_points(out, conv); }
 int ekf_get_search_ellipses(ekf_filter* f, int sigma_size, int* out) { IMPL_OR_ARG(f); if (!out) return EKF_ERR_ARG; return f->impl->search_ellipses(sigma_size, out); }
 int ekf_ransac_1point(ekf_filter* f, const void* z, const int* idx, int M, double thr, int* counts,
                       unsigned char* inl, int* best) {

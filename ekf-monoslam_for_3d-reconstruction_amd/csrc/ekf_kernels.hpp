@@ -676,6 +676,54 @@ __global__ void k_ransac_count(const unsigned char* __restrict__ mask, int M, in
   counts[k] = c;
 }
 
+// f3: map export, one lane per feature: the N x 12 table of RosVSLAM::getPointsFeatures
+// (RosVSLAMRansac.cpp:340-418): [X Y Z] * map_scale, then the 3x3 covariance block row by row.
+// The reference fills rows of XYZ features only (inverse-depth rows stay zero, :360-375); with
+// `convert_inverse_depth` those rows get inverseDepth2XyzWorld(f) and Jf Sigma_ff Jf^T instead
+// (what its marker code does, :171-183).
+template <typename T>
+__global__ void k_export_points(const T* __restrict__ mu, const T* __restrict__ S, int ld,
+                                const int* __restrict__ pos, const int* __restrict__ coding, int N,
+                                T map_scale, int convert_inverse_depth, T* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  T* o = out + (size_t)i * 12;
+  const int p = pos[i];
+  if (coding[i] != 0) {
+    for (int k = 0; k < 3; ++k) o[k] = mu[p + k] * map_scale;
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) o[3 + a * 3 + b] = S[(size_t)(p + a) * ld + p + b];
+    return;
+  }
+  if (!convert_inverse_depth) {
+    for (int k = 0; k < 12; ++k) o[k] = T(0);
+    return;
+  }
+  const T theta = mu[p + 3], phi = mu[p + 4], ro = mu[p + 5];
+  const T st = t_sin(theta), ct = t_cos(theta), sp = t_sin(phi), cp = t_cos(phi);
+  const T m[3] = {st * cp, -sp, ct * cp};
+  T J[18];
+  for (int k = 0; k < 18; ++k) J[k] = T(0);
+  J[0] = T(1); J[7] = T(1); J[14] = T(1);
+  J[3] = ct * cp / ro;   J[9] = T(0);      J[15] = -st * cp / ro;
+  J[4] = -st * sp / ro;  J[10] = -cp / ro; J[16] = -ct * sp / ro;
+  J[5] = -m[0] / (ro * ro); J[11] = -m[1] / (ro * ro); J[17] = -m[2] / (ro * ro);
+  for (int k = 0; k < 3; ++k) o[k] = (mu[p + k] + m[k] / ro) * map_scale;
+  T JS[18];
+  for (int a = 0; a < 3; ++a)
+    for (int c = 0; c < 6; ++c) {
+      T acc = T(0);
+      for (int k = 0; k < 6; ++k) acc += J[a * 6 + k] * S[(size_t)(p + k) * ld + p + c];
+      JS[a * 6 + c] = acc;
+    }
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) {
+      T acc = T(0);
+      for (int k = 0; k < 6; ++k) acc += JS[a * 6 + k] * J[b * 6 + k];
+      o[3 + a * 3 + b] = acc;
+    }
+}
+
 template <typename T>
 __global__ void k_fill(T* __restrict__ p, size_t count, T v) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)

@@ -182,6 +182,12 @@ class VSlamFilter:
                                                         int(bool(plane_constraint)), self._ptr(out)))
         return out.T.copy()
 
+    def getPointsFeatures(self, convert_inverse_depth: bool = False):
+        """RosVSLAM::getPointsFeatures (RosVSLAMRansac.cpp:340-418): (N, 12) = xyz * map_scale + 3x3 covariance."""
+        out = np.zeros((self.numOfFeatures(), 12), self.dtype)
+        self._check(self._lib.ekf_export_points(self._h, self._ptr(out), int(bool(convert_inverse_depth))))
+        return out
+
     def searchEllipses(self, sigma_size: Optional[int] = None):
         """computeEllipsoidParameters (vR.cpp:1368-1382): (N,3) ints (a, b, theta_deg) per feature."""
         N = self.numOfFeatures()

@@ -182,6 +182,12 @@ int ekf_covariance_parameter(ekf_filter* f, double* out);
  * RosVSLAMRansac.cpp:177-183): world point (3) and 3x3 covariance (column-major). */
 int ekf_feature_xyz(ekf_filter* f, int index, void* xyz, void* cov3x3);
 
+/* RosVSLAM::getPointsFeatures (RosVSLAMRansac.cpp:340-418), the table behind `points.txt`: one row of
+ * 12 scalars per feature, ROW-MAJOR N x 12: [X Y Z] * map_scale (mu[13]; 1 for camera_dim 13), then the
+ * 3x3 covariance block row by row.  The reference fills the rows of XYZ features only; with
+ * convert_inverse_depth != 0 the inverse-depth rows carry inverseDepth2XyzWorld(f) and Jf Sigma Jf^T. */
+int ekf_export_points(ekf_filter* f, void* out, int convert_inverse_depth);
+
 /* Per-kernel HIP-event timing (EKF_OPT_PROFILE).  Kernel ids are dense in
  * [0, ekf_profile_kernels()). */
 int ekf_profile_kernels(void);
