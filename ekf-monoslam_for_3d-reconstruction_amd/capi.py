@@ -65,6 +65,7 @@ _PROTOS = {
     "ekf_get_predictions": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "ekf_update": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
     "ekf_update_device": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
+    "ekf_rescue_high_innovation": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_double, _P]),
     "ekf_export_points": (C.c_int, [_P, _P, C.c_int]),
     "ekf_get_search_ellipses": (C.c_int, [_P, C.c_int, _P]),
     "ekf_ransac_1point": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, _P, _P, C.POINTER(C.c_int)]),

@@ -80,6 +80,7 @@ struct FilterBase {
   virtual void* dev_mu() = 0;
   virtual void* dev_sigma(int*) = 0;
   virtual int export_points(void*, int) = 0;
+  virtual int rescue(const void*, const void*, const int*, int, double, unsigned char*) = 0;
   virtual int search_ellipses(int, int*) = 0;
   virtual int ransac(const void*, const int*, int, double, int*, unsigned char*, int*) = 0;
   virtual int shard_configure(int, int) = 0;
@@ -970,6 +971,35 @@ struct Filter : FilterBase {
   unsigned char* d_rmask = nullptr;      // M x M inlier mask
   size_t rmask_bytes = 0;
 
+  int rescue(const void* cam_before, const void* z, const int* idx, int M, double thr, unsigned char* out) override {
+    HIPCHK(hipSetDevice(device));
+    if (M <= 0) return EKF_OK;
+    if (M > N || !cam_before || !z || !idx || !out) FAIL(EKF_ERR_ARG, "bad arguments");
+    for (int k = 0; k < M; ++k)
+      if (idx[k] < 0 || idx[k] >= N) FAIL(EKF_ERR_ARG, "feature index out of range");
+    int rc = sync_layout();
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(d_z, z, (size_t)2 * M * sizeof(T), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(d_midx, idx, (size_t)M * sizeof(int), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(d_tmp, cam_before, 7 * sizeof(T), hipMemcpyHostToDevice, stream));
+    sh_ident = -1;
+    if (!d_ibuf) HIPCHK(hipMalloc(&d_ibuf, (size_t)std::max(capN, 1) * 3 * sizeof(int)));
+    unsigned char* d_out = reinterpret_cast<unsigned char*>(d_ibuf);
+    {
+      Scope sc(this, KID_MEASURE);
+      k_measure<T><<<(M + 63) / 64, 64, 0, stream>>>(mu(), d_pos, d_coding, 0, N, cam, d_h, d_Hc, d_Hf, d_flags, d_midx, M,
+                                                    d_tmp);
+      k_measure_sd<T><<<(16 * M + 255) / 256, 256, 0, stream>>>(S(), ld, d_pos, d_coding, 0, N, T(0), d_Hc, d_Hf, d_Sd,
+                                                               d_midx, M);
+      k_chi2_gate<T><<<(M + 127) / 128, 128, 0, stream>>>(d_h, d_Sd, d_z, d_midx, M, T(thr), d_out);
+    }
+    HIPCHK(hipMemcpyAsync(out, d_out, M, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    have_meas = true;          // the listed features carry fresh h / H (the others keep older ones)
+    have_sd = false;           // the 2x2 blocks just written have no measurement noise: not the St blocks
+    return EKF_OK;
+  }
+
   T* d_pts = nullptr;
   int export_points(void* out, int convert) override {
     HIPCHK(hipSetDevice(device));
@@ -1380,6 +1410,11 @@ const char* ekf_profile_kernel_name(int kid) { return (kid >= 0 && kid < ekf::KI
 int ekf_profile_read(ekf_filter* f, int kid, double* ms, long long* cnt) { IMPL_OR_ARG(f); return f->impl->profile_read(kid, ms, cnt); }
 int ekf_profile_reset(ekf_filter* f) { IMPL_OR_ARG(f); return f->impl->profile_reset(); }
 
+int ekf_rescue_high_innovation(ekf_filter* f, const void* cam, const void* z, const int* idx, int M, double thr,
+                               unsigned char* out) {
+  IMPL_OR_ARG(f);
+  return f->impl->rescue(cam, z, idx, M, thr, out);
+}
 int ekf_export_points(ekf_filter* f, void* out, int conv) { IMPL_OR_ARG(f); if (!out) return EKF_ERR_ARG; return f->impl->export_points(out, conv); }
 int ekf_get_search_ellipses(ekf_filter* f, int sigma_size, int* out) { IMPL_OR_ARG(f); if (!out) return EKF_ERR_ARG; return f->impl->search_ellipses(sigma_size, out); }
 int ekf_ransac_1point(ekf_filter* f, const void* z, const int* idx, int M, double thr, int* counts,

@@ -259,19 +259,29 @@ __global__ void k_propagate_streaming(const T* __restrict__ src, T* __restrict__
 // a4 / a5 / a6: one lane per feature: h, compact H (2x7 + 2x6), flags.  flags bit0 = visible (vR.cpp:529), bit1 = rho <= 0 (vR.cpp:517-521).
 // Hc: [N][2][7], Hf: [N][2][6] row-major (XYZ features: last 3 columns zero).
 // ---------------------------------------------------------------------------------------
+// `list` (count entries) restricts the sweep to the listed features; `cam_pose` (r, q: 7 scalars)
+// overrides the camera part of mu -- the high-innovation rescue linearises the features of the UPDATED
+// state around the camera pose of the state BEFORE the first update (vR.cpp:1069-1072, 1085).
 template <typename T>
 __global__ void k_measure(const T* __restrict__ mu,
                           const int* __restrict__ pos, const int* __restrict__ coding, int f_begin, int N,
                           CamParams cam,
                           T* __restrict__ h_out, T* __restrict__ Hc, T* __restrict__ Hf,
-                          unsigned char* __restrict__ flags) {
-  const int i = f_begin + blockIdx.x * blockDim.x + threadIdx.x;   // features [f_begin, N)
+                          unsigned char* __restrict__ flags,
+                          const int* __restrict__ list = nullptr, int count = 0,
+                          const T* __restrict__ cam_pose = nullptr) {
+  int i = f_begin + blockIdx.x * blockDim.x + threadIdx.x;   // features [f_begin, N) or list[0..count)
+  if (list) {
+    if (i >= count) return;
+    i = list[i];
+  }
   if (i >= N) return;
   const int p = pos[i];
   const bool xyz = coding[i] != 0;
   const int fs = xyz ? 3 : 6;
-  const T r[3] = {mu[0], mu[1], mu[2]};
-  const T qc[4] = {mu[3], -mu[4], -mu[5], -mu[6]};   // complement, vR.cpp:493
+  const T* cp7 = cam_pose ? cam_pose : mu;
+  const T r[3] = {cp7[0], cp7[1], cp7[2]};
+  const T qc[4] = {cp7[3], -cp7[4], -cp7[5], -cp7[6]};   // complement, vR.cpp:493
   T R[9];
   quat2rot(qc, R);
   T f[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
@@ -340,11 +350,16 @@ __global__ void k_measure(const T* __restrict__ mu,
 template <typename T>
 __global__ void k_measure_sd(const T* __restrict__ S, int ld, const int* __restrict__ pos,
                              const int* __restrict__ coding, int f_begin, int N, T r_pix,
-                             const T* __restrict__ Hc, const T* __restrict__ Hf, T* __restrict__ Sd) {
+                             const T* __restrict__ Hc, const T* __restrict__ Hf, T* __restrict__ Sd,
+                             const int* __restrict__ list = nullptr, int count = 0) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = f_begin + (gid >> 4);
+  int i = f_begin + (gid >> 4);
   const int a = gid & 15;
-  const bool live = i < N;
+  bool live = i < N;
+  if (list) {
+    live = (gid >> 4) < count;
+    i = live ? list[gid >> 4] : f_begin;
+  }
   const int fi = live ? i : f_begin;
   const int p = pos[fi];
   const int fs = coding[fi] ? 3 : 6;
@@ -722,6 +737,21 @@ __global__ void k_export_points(const T* __restrict__ mu, const T* __restrict__ 
       for (int k = 0; k < 6; ++k) acc += JS[a * 6 + k] * J[b * 6 + k];
       o[3 + a * 3 + b] = acc;
     }
+}
+
+// High-innovation gate (vR.cpp:1113-1114): (h - z)^T S_hi^-1 (h - z) <= thr with S_hi = H Sigma H^T
+// (no measurement noise), one lane per listed feature.
+template <typename T>
+__global__ void k_chi2_gate(const T* __restrict__ h, const T* __restrict__ Sd, const T* __restrict__ z,
+                            const int* __restrict__ list, int count, T thr, unsigned char* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  const int i = list[k];
+  const T e0 = h[2 * i] - z[2 * k], e1 = h[2 * i + 1] - z[2 * k + 1];
+  const T s00 = Sd[4 * i], s01 = Sd[4 * i + 1], s10 = Sd[4 * i + 2], s11 = Sd[4 * i + 3];
+  const T det = s00 * s11 - s01 * s10;
+  const T q = (e0 * (s11 * e0 - s01 * e1) + e1 * (-s10 * e0 + s00 * e1)) / det;
+  out[k] = (q <= thr) ? 1 : 0;
 }
 
 template <typename T>

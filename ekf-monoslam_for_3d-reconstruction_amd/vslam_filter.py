@@ -182,6 +182,17 @@ class VSlamFilter:
                                                         int(bool(plane_constraint)), self._ptr(out)))
         return out.T.copy()
 
+    def rescueHighInnovation(self, cam_before, z, indices, chi2_threshold: float = 1.0):
+        """High-innovation rescue (vR.cpp:1066-1117): re-linearise the listed features and gate them."""
+        cam = np.ascontiguousarray(cam_before, self.dtype).reshape(-1)[:7].copy()
+        z = np.ascontiguousarray(z, self.dtype).reshape(-1)
+        idx = np.ascontiguousarray(indices, np.int32)
+        out = np.zeros(idx.size, np.uint8)
+        if idx.size:
+            self._check(self._lib.ekf_rescue_high_innovation(self._h, self._ptr(cam), self._ptr(z), self._ptr(idx),
+                                                             idx.size, float(chi2_threshold), self._ptr(out)))
+        return out.astype(bool)
+
     def getPointsFeatures(self, convert_inverse_depth: bool = False):
         """RosVSLAM::getPointsFeatures (RosVSLAMRansac.cpp:340-418): (N, 12) = xyz * map_scale + 3x3 covariance."""
         out = np.zeros((self.numOfFeatures(), 12), self.dtype)

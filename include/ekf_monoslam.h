@@ -151,6 +151,15 @@ int ekf_get_search_ellipses(ekf_filter* f, int sigma_size, int* out);
 int ekf_ransac_1point(ekf_filter* f, const void* z, const int* indices, int M, double threshold,
                       int* counts, unsigned char* inliers_of_best, int* best);
 
+/* High-innovation rescue (vR.cpp:1066-1117), after the low-innovation update: for the listed features
+ * (matched but not low-innovation inliers) h / H are re-evaluated with the feature entries of the CURRENT
+ * (updated) state and the camera pose `cam_before` = mu[0:7] of the state BEFORE that update (the
+ * reference's choice, :1069-1072), S_hi = H Sigma H^T without measurement noise (:1113), and
+ * is_hi[k] = ((h - z)^T S_hi^-1 (h - z) <= chi2_threshold) (the reference uses 1, :1066).  The listed
+ * features keep the new h / H, so a following ekf_update over the rescued ones uses them (:1119-1130). */
+int ekf_rescue_high_innovation(ekf_filter* f, const void* cam_before, const void* z, const int* indices,
+                               int M, double chi2_threshold, unsigned char* is_hi);
+
 /* Full St for a measured set (vR.cpp:598): out is m x m column-major, m = 2M (+3). */
 int ekf_innovation_covariance(ekf_filter* f, const int* indices, int M, int plane_constraint,
                               void* S_out);

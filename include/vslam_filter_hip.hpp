@@ -53,6 +53,36 @@ class VSlamFilterHip {
     check(ekf_update(h_, z.data(), indices.data(), (int)indices.size(), forsePlane ? 1 : 0));
   }
   void measure() { check(ekf_measure(h_)); }   // recompute h/H at the current state (vR.cpp:1080-1117)
+  // The image-independent pieces of the reference's two-stage update() (vR.cpp:964-1130):
+  // every 1-point hypothesis on the device; returns the index (into `indices`) of the best one.
+  int ransac1Point(const std::vector<float>& z, const std::vector<int>& indices, double threshold_px,
+                   std::vector<int>& counts, std::vector<unsigned char>& inliers_of_best) {
+    const int M = (int)indices.size();
+    int best = -1;
+    counts.resize(M); inliers_of_best.resize(M);
+    check(ekf_ransac_1point(h_, z.data(), indices.data(), M, threshold_px, counts.data(), inliers_of_best.data(), &best));
+    return best;
+  }
+  // high-innovation rescue after the low-innovation update; cam_before = mu[0:7] before that update
+  std::vector<unsigned char> rescueHighInnovation(const float cam_before[7], const std::vector<float>& z,
+                                                  const std::vector<int>& indices, double chi2_threshold = 1.0) {
+    std::vector<unsigned char> hi(indices.size());
+    check(ekf_rescue_high_innovation(h_, cam_before, z.data(), indices.data(), (int)indices.size(), chi2_threshold,
+                                     hi.data()));
+    return hi;
+  }
+  // drawPrediction's ellipse parameters (vR.cpp:1368-1382): 5 ints per feature
+  std::vector<int> searchEllipses(int sigma_size) {
+    std::vector<int> e(5 * (size_t)numOfFeatures());
+    check(ekf_get_search_ellipses(h_, sigma_size, e.data()));
+    return e;
+  }
+  // the N x 12 table behind points.txt (RosVSLAM::getPointsFeatures, RosVSLAMRansac.cpp:340-418)
+  std::vector<float> getPointsFeatures(bool convert_inverse_depth = true) {
+    std::vector<float> t(12 * (size_t)numOfFeatures());
+    check(ekf_export_points(h_, t.data(), convert_inverse_depth ? 1 : 0));
+    return t;
+  }
 
   std::vector<float> getState() {              // VectorXf(14), vR.cpp:135-140
     std::vector<float> s(STATE_DIM);

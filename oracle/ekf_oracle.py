@@ -765,6 +765,28 @@ def ransac_1point(filt, z, indices, threshold=None):
     return mask.sum(axis=1).astype(np.int32), mask
 
 
+def rescue_high_innovation(filt, mu_before, z, indices, threshold=1.0, return_chi2=False):
+    """vR.cpp:1066-1117: h / H of the listed features from the features of the updated state `filt.mu`
+    and the camera pose of `mu_before`; S_hi = H Sigma H^T (no R); chi-square gate.  Stores the new
+    h / Hc / Hf in the features (patches[i].h / .H, :1089-1110) and returns the is-in-Hi flags."""
+    T = filt.T
+    z = np.asarray(z, T).reshape(-1, 2)
+    r = np.asarray(mu_before[0:3], T)
+    q = np.asarray(mu_before[3:7], T)
+    out = np.zeros(len(indices), bool)
+    chi2 = np.zeros(len(indices), T)
+    for k, i in enumerate(indices):
+        ft = filt.features[i]
+        hi, Hc, Hf, vis, rem = filt.measure_feature(ft, mu=filt.mu, r=r, q=q)
+        ft.h, ft.Hc, ft.Hf = hi, Hc, Hf
+        H = filt.dense_H([i])
+        S_hi = H @ filt.Sigma @ H.T                                                  # :1113
+        e = hi - z[k]
+        chi2[k] = T(e @ np.linalg.inv(S_hi) @ e)
+        out[k] = bool(chi2[k] <= T(threshold))                                       # :1114
+    return (out, chi2) if return_chi2 else out
+
+
 # --------------------------------------------------------------------------
 # structured filter: identical arithmetic, identity blocks exploited
 # --------------------------------------------------------------------------

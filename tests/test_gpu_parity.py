@@ -370,3 +370,39 @@ def test_full_size_properties_n1000():
     assert full.shape == (6014, 6014) and np.abs(full - full.T).max() <= 1e-6 * np.abs(full).max()
     w = np.linalg.eigvalsh(full[:200, :200].astype(np.float64))
     assert w.min() > -1e-6 * w.max()                  # leading block stays positive semi-definite
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_two_stage_update_with_rescue(dtype):          # vR.cpp:964-1130, 1245-1284: the whole update() flow
+    ref, g = make_pair(24, dtype)
+    ref.predict()
+    g.predict()
+    vis = ref.visible_indices()
+    z = o.synthetic_measurements(ref, vis, sigma=1.0).reshape(-1, 2)
+    z[5] += 7.0                                        # outside 2 sigma_px of the prediction, inside the chi2 gate
+    z[9] += 60.0                                       # a gross mismatch: never rescued
+    counts, best, inl = g.ransac1Point(z, vis)
+    counts_ref, mask_ref = o.ransac_1point(ref, z, vis)
+    assert (inl != mask_ref[best]).sum() == 0 and not inl[5] and not inl[9]
+    mu_before = ref.mu.copy()
+    cam_before = g.getState()[:7]
+    li = [vis[k] for k in range(len(vis)) if inl[k]]
+    ref.update(z[inl].reshape(-1), li)
+    g.update(z[inl].reshape(-1), li)
+    rest = [vis[k] for k in range(len(vis)) if not inl[k]]
+    hi1_ref, chi2 = o.rescue_high_innovation(ref, mu_before, z[~inl], rest, return_chi2=True)
+    assert list(g.rescueHighInnovation(cam_before, z[~inl], rest)) == list(hi1_ref)     # the reference's gate (1)
+    # the reference's gate is tight (S_hi carries no pixel noise); place it between the two outliers so
+    # that both outcomes are exercised
+    thr = float(np.sqrt(chi2[rest.index(vis[5])] * chi2[rest.index(vis[9])]))
+    hi_ref = o.rescue_high_innovation(ref, mu_before, z[~inl], rest, threshold=thr)
+    hi = g.rescueHighInnovation(cam_before, z[~inl], rest, thr)
+    assert list(hi) == list(hi_ref)
+    assert hi[rest.index(vis[5])] and not hi[rest.index(vis[9])]
+    sel = [rest[k] for k in range(len(rest)) if hi[k]]
+    zz = z[~inl][hi].reshape(-1)
+    ref.update(zz, sel)
+    g.update(zz, sel)
+    mu, S = gpu_state(g)
+    t = TOL[dtype]
+    assert relf(mu, ref.mu) < t["mu"] * 10 and relf(S, ref.Sigma) < t["S"] * 2
