@@ -37,6 +37,7 @@ enum KernelId : int {
   KID_ADD_FEATURE,
   KID_COMPACT,
   KID_MISC,
+  KID_WUPDATE,
   KID_COUNT
 };
 
@@ -44,7 +45,8 @@ static const char* kKernelNames[KID_COUNT] = {
     "predict_camera",  "propagate_strips", "propagate_streaming", "measure",
     "innovation",      "sigma_ht",         "innovation_cov",      "chol_diag",
     "chol_panel",      "chol_trailing",    "state_update",        "downdate_syrk",
-    "solve_trmm",      "normalize_quat",  "add_feature",      "compact_transform",   "misc"};
+    "solve_trmm",      "normalize_quat",  "add_feature",      "compact_transform",   "misc",
+    "w_update"};
 
 static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
@@ -156,6 +158,9 @@ struct Filter : FilterBase {
   hipStream_t stream_b = nullptr, stream_c = nullptr;   // solve pieces / downdate pieces, overlapped with the chain
   hipEvent_t ev_chain[8] = {}, ev_solve[8] = {}, ev_b = nullptr, ev_c = nullptr;
   int opt_split16 = 8;
+  int opt_chain_mask = 0;                               // 1: chain of chunks >= 1 on the reserved CUs only (measured slower: the trailing updates want more CUs)
+  int last_nchunks = 1, last_cend[8] = {};
+  int env_chunks[8] = {}, env_nchunks = 0;               // EKF_CHUNKS="5,10,14,16": tuning knob (block steps)
   int opt_pipeline = -1;                                 // -1 auto: on when the chain has >= 8 block steps
   int* d_tilemap = nullptr;                             // work lists: [lower-tri super-tiles | solve heavy-first]
   int tilemap_nt = 0, tilemap_ntc = 0, tri_count = 0, solve_off = 0;
@@ -197,8 +202,7 @@ struct Filter : FilterBase {
   bool prof_on(int kid) const {
     if (opt_profile >= 2) return true;
     if (opt_profile == 1)
-      return kid == KID_DOWNDATE || kid == KID_PROPAGATE_STREAMING || kid == KID_PROPAGATE_STRIPS ||
-             kid == KID_SIGMA_HT || kid == KID_SOLVE;
+      return kid == KID_DOWNDATE || kid == KID_PROPAGATE_STREAMING || kid == KID_PROPAGATE_STRIPS;
     return false;
   }
   hipEvent_t get_event() {
@@ -311,7 +315,18 @@ struct Filter : FilterBase {
       std::vector<uint32_t> mask((num_cus + 31) / 32, 0xffffffffu);
       for (int i = 0; i < reserved_cus; ++i) mask[i / 32] &= ~(1u << (i % 32));
       HIPCHK(hipExtStreamCreateWithCUMask(&stream_b, (uint32_t)mask.size(), mask.data()));
-      HIPCHK(hipExtStreamCreateWithCUMask(&stream_c, (uint32_t)mask.size(), mask.data()));
+      // chain stream: ONLY the reserved CUs, so that a chain workgroup never lands next to tile-GEMM waves
+      std::vector<uint32_t> cmask((num_cus + 31) / 32, 0u);
+      for (int i = 0; i < reserved_cus; ++i) cmask[i / 32] |= (1u << (i % 32));
+      HIPCHK(hipExtStreamCreateWithCUMask(&stream_c, (uint32_t)cmask.size(), cmask.data()));
+      if (const char* e = getenv("EKF_CHAIN_MASK")) opt_chain_mask = atoi(e);
+      if (const char* e = getenv("EKF_CHUNKS")) {           // tuning knob: chunk ends in block steps
+        for (const char* q = e; *q && env_nchunks < 8;) {
+          env_chunks[env_nchunks++] = atoi(q);
+          while (*q && *q != ',') ++q;
+          if (*q == ',') ++q;
+        }
+      }
     }
     // mu0 / Sigma0 (vR.cpp:163-180, 211-216)
     std::vector<T> mu0(camera_dim, T(0));
@@ -600,9 +615,9 @@ struct Filter : FilterBase {
   template <int ROLE, bool BT, int TM = 128, int TN = 128>
   void gemm(const T* A, int lda, const T* B, int ldb, T* C, int ldc, int rows, int cols, int K, T alpha, T beta,
             int tri, int row_off, int col_off, int ktri, int ktile_off = 0, hipStream_t st = nullptr,
-            const int* tile_list = nullptr, int ntiles = 0) {
+            const int* tile_list = nullptr, int ntiles = 0, int zrow = 0, int zcol_end = 0) {
     GemmArgs g{A, lda, B, ldb, C, ldc, K, double(alpha), double(beta), tri, row_off, col_off, ktri, ktile_off,
-               nullptr, 0, nullptr};
+               nullptr, 0, nullptr, zrow, zcol_end, (ROLE == ROLE_DOWNDATE) ? 1 : 0};
     if (!st) st = stream;
     const bool mf = kIsF32 && opt_mfma;
     dim3 grid(cols / (mf ? TN : 64), rows / (mf ? TM : 64));
@@ -611,7 +626,7 @@ struct Filter : FilterBase {
       g.ntiles = ntiles;
       g.counter = d_counters + counter_next++;
       // persistent grid: two workgroups per CU the stream may use
-      const bool side = (st == stream_b || st == stream_c);
+      const bool side = (st == stream_b);
       const int wgs = 2 * (side ? (num_cus - reserved_cus) : num_cus);
       grid = dim3(std::min(ntiles, wgs), 1);
     }
@@ -652,8 +667,39 @@ struct Filter : FilterBase {
     return EKF_OK;
   }
 
+  // Chunk ends (in block steps) of the factorisation.  One chunk = the plain algorithm (the strip is the
+  // whole inverse); several chunks when the chain is long enough to be worth hiding.
+  int plan_chunks(int nsteps, int* cend) const {
+    const bool pipe = (opt_pipeline < 0) ? (nsteps >= 8) : (opt_pipeline != 0);
+    if (!pipe || nsteps < 2 || !stream_b) { cend[0] = nsteps; return 1; }
+    if (env_nchunks > 0 && env_chunks[env_nchunks - 1] == nsteps) {
+      for (int g = 0; g < env_nchunks; ++g) cend[g] = env_chunks[g];
+      return env_nchunks;
+    }
+    if (opt_pipeline < 2) {
+      // default: three chunks ending at 1/4, 5/8 and 1 of the chain (tools/sweep_chunks.sh: the first chunk is
+      // exposed, so it is short; every further chunk re-reads Sigma once in its downdate, so there are few)
+      static const int kEnd16[3] = {4, 10, 16};
+      int k = 0, prev = 0;
+      for (int g = 0; g < 3; ++g) {
+        int e = (g == 2) ? nsteps : (nsteps * kEnd16[g] + 8) / 16;
+        if (e > prev) { cend[k++] = e; prev = e; }
+      }
+      return k;
+    }
+    const int want = std::min(std::min(opt_pipeline, 8), nsteps);
+    int k = 0, prev = 0;
+    for (int g = 0; g < want; ++g) {
+      int e = (int)(((long long)nsteps * (g + 1) + want - 1) / want);
+      if (g + 1 == want) e = nsteps;
+      if (e > prev) { cend[k++] = e; prev = e; }
+    }
+    return k;
+  }
+
   // W, S (and nu) for a measured set already resident in d_midx / d_z.
-  int build_innovation(int M, int plane, bool with_nu, int* m_out, int* m_pad_out, bool with_identity = false) {
+  int build_innovation(int M, int plane, bool with_nu, int* m_out, int* m_pad_out, const ChunkTab* tab = nullptr,
+                       int strip_rows = 0) {
     const int nb = NB();
     const int m = 2 * M + (plane ? 3 : 0);
     const int m_pad = round_up(m, nb);
@@ -691,17 +737,18 @@ struct Filter : FilterBase {
     }
     {
       Scope sc(this, KID_INNOVATION_COV);
-      T* zid = with_identity ? d_Y + (size_t)m_pad * ldy : nullptr;
+      T* zid = tab ? d_Y + (size_t)m_pad * ldy : nullptr;
+      const ChunkTab ct = tab ? *tab : ChunkTab{0, {}};
       if (small) {
         constexpr int KB = 1;
         dim3 grid((m_pad + 255) / 256, std::max(1, (M + KB - 1) / KB));
         k_innovation_cov<T, KB><<<grid, 256, 0, stream>>>(d_W, ldy, d_Hc, d_Hf, d_pos, d_coding, ip, M, plane,
-                                                        T(sigma_pixel_2), T(0.00001), d_Y, m_pad, 0, M, zid);
+                                                        T(sigma_pixel_2), T(0.00001), d_Y, m_pad, 0, M, zid, ct, strip_rows);
       } else {
         constexpr int KB = 8;
         dim3 grid((m_pad + 255) / 256, std::max(1, (M + KB - 1) / KB));
         k_innovation_cov<T, KB><<<grid, 256, 0, stream>>>(d_W, ldy, d_Hc, d_Hf, d_pos, d_coding, ip, M, plane,
-                                                        T(sigma_pixel_2), T(0.00001), d_Y, m_pad, 0, M, zid);
+                                                        T(sigma_pixel_2), T(0.00001), d_Y, m_pad, 0, M, zid, ct, strip_rows);
       }
     }
     HIPCHK(hipGetLastError());
@@ -733,26 +780,32 @@ struct Filter : FilterBase {
         sh_ident = -1;
       }
     }
-    int m = 0, m_pad = 0;
-    int rc = build_innovation(M, plane, true, &m, &m_pad, true);
+    const int nb = NB();
+    int m = 2 * M + (plane ? 3 : 0), m_pad = round_up(m, nb);
+    const int npad_live = round_up(n, nb);
+    // Blocked right-looking Cholesky of S in column chunks (a few block steps each).  Chunk g carries its
+    // own identity block under S (the strip, rows m_pad..), which the same panel / trailing sweeps turn
+    // into Z_gg = L_gg^-T: the inverse of the DIAGONAL chunk only.  As soon as the chain has left chunk g
+    // the rest runs on the second stream, off the chain's CUs:
+    //   solve       V_g = [W_g; nu_g^T] Z_gg                         (K stops at the diagonal)
+    //   W update    [W; nu^T][:, c1:] -= V_g L[c1:, c0:c1]^T         (right-looking, rank = chunk width)
+    //   downdate    Sigma -= V_g V_g^T
+    // so only the last chunk's solve + downdate are exposed after the chain.
+    const int nsteps = m_pad / nb;
+    int cend[8];
+    const int nchunks = plan_chunks(nsteps, cend);
+    ChunkTab tab{nchunks, {}};
+    int strip_rows = 0;
+    for (int g = 0; g < nchunks; ++g) {
+      tab.end[g] = cend[g] * nb;
+      strip_rows = std::max(strip_rows, (cend[g] - (g ? cend[g - 1] : 0)) * nb);
+    }
+    int rc = build_innovation(M, plane, true, &m, &m_pad, &tab, strip_rows);
     cur_z = nullptr;
     cur_midx = nullptr;
     if (rc) return rc;
-    const int nb = NB();
-    const int npad_live = round_up(n, nb);
     T* Y = d_Y;
-    T* Z = d_Y + (size_t)m_pad * ldy;
-    // tall blocked right-looking Cholesky: [S; I] -> [L; Z = L^-T].  At step j the rows that can
-    // change are S rows below the diagonal block plus Z rows of block 0..j: always m_pad rows.
-    // The chain is serial and small; the two large contractions are cut into column groups of
-    // Z / V and run on a second stream as soon as their group of the chain is final:
-    //   solve piece g     V[:, g] = [W; nu^T] Z[:, g]        (K stops at the diagonal)
-    //   downdate piece g  Sigma  -= V[:, g] V[:, g]^T
-    const int nsteps = m_pad / nb;
-    // opt_pipeline: -1 auto, 0/1 off/on (default group count), k >= 2: k column groups
-    const bool pipe = (opt_pipeline < 0) ? (nsteps >= 8) : (opt_pipeline != 0);
-    const int want = (opt_pipeline >= 2) ? std::min(opt_pipeline, 8) : 2;     // 2 groups measured best (tools/sweep_groups.sh)
-    const int ngroups = pipe ? std::min(want, nsteps) : 1;
+    T* Zs = d_Y + (size_t)m_pad * ldy;                     // the strip
     const int tile = (kIsF32 && opt_mfma) ? 128 : 64;
     const int ntr = (npad_live + nb) / tile, ntc = m_pad / tile;
     rc = ensure_tilemap(npad_live / tile, ntr, ntc);
@@ -760,68 +813,88 @@ struct Filter : FilterBase {
 
     int step = 0;
     bool b_inflight = false;
-    for (int gi = 0; gi < ngroups; ++gi) {
-      // uneven column groups: the last one has nothing to hide behind, so it is the smallest
-      static const int kGroupEnd16[4] = {4, 8, 12, 16};
-      int step_end = (ngroups == 4) ? (nsteps * kGroupEnd16[gi] + 15) / 16 : (int)((long long)nsteps * (gi + 1) / ngroups);
-      if (ngroups == 2 && gi == 0) step_end = (nsteps * opt_split16 + 15) / 16;   // first group: opt_split16 / 16 of the chain
-      step_end = std::min(nsteps, std::max(step_end, step));
-      if (gi + 1 == ngroups) step_end = nsteps;
-      if (step_end == step) continue;                      // empty group (few steps)
-      const int col_begin = step * nb;
-      for (; step < step_end; ++step) {
+    bool c_inflight = false;
+    for (int gi = 0; gi < nchunks; ++gi) {
+      const int c0 = step * nb, c1 = cend[gi] * nb;
+      // chunk 0 has the chip to itself; later chunks run beside the tile GEMMs of stream_b, on the reserved CUs
+      hipStream_t sc_ = (opt_chain_mask && nchunks > 1 && gi > 0) ? stream_c : stream;
+      if (sc_ != stream && !c_inflight) {
+        HIPCHK(hipStreamWaitEvent(stream_c, ev_chain[0], 0));      // recorded below, after chunk 0
+        c_inflight = true;
+      }
+      for (; step < cend[gi]; ++step) {
         const int j = step * nb;
         T* Ajj = Y + (size_t)j * ldy + j;
         T* Dj = d_Dinv + (size_t)step * nb * nb;
         {
-          Scope sc(this, KID_CHOL_DIAG);
+          Scope sc(this, KID_CHOL_DIAG, sc_);
           if (nb == 128) {
             if constexpr (kIsF32)
-              k_chol_diag_packed<><<<1, 512, 0, stream>>>(Ajj, ldy, Dj, d_status);
+              k_chol_diag_packed<><<<1, 512, 0, sc_>>>(Ajj, ldy, Dj, d_status);
           } else {
-            k_chol_diag<T, 64><<<1, 512, diag_lds(64), stream>>>(Ajj, ldy, Dj, d_status);
+            k_chol_diag<T, 64><<<1, 512, diag_lds(64), sc_>>>(Ajj, ldy, Dj, d_status);
           }
         }
-        const int r0 = j + nb;                            // first row below the diagonal block
+        // rows that change at this step: S rows below the diagonal block, then strip rows [0, r0 - c0)
+        // (Z rows c0..r0 of this chunk): contiguous, m_pad - c0 of them starting at row r0
+        const int r0 = j + nb;
+        const int vrows = m_pad - c0;
         {
-          Scope sc(this, KID_CHOL_PANEL);                 // P = Y[r0:r0+m_pad, j:j+nb] * Linv_jj^T, in place
+          Scope sc(this, KID_CHOL_PANEL, sc_);                 // P = Y[r0.., j:j+nb] * Linv_jj^T, in place
           T* P = Y + (size_t)r0 * ldy + j;
-          gemm<ROLE_PANEL, false, 64, 128>(P, ldy, Dj, nb, P, ldy, m_pad, nb, nb, T(1), T(0), 0, 0, 0, 0);
+          gemm<ROLE_PANEL, false, 64, 128>(P, ldy, Dj, nb, P, ldy, vrows, nb, nb, T(1), T(0), 0, 0, 0, 0, 0, sc_);
         }
         if (r0 < m_pad) {
-          Scope sc(this, KID_CHOL_TRAILING);              // Y[r0:r0+m_pad, r0:m_pad] -= P P_S^T
+          Scope sc(this, KID_CHOL_TRAILING, sc_);              // Y[r0.., r0:] -= P P_S^T; strip rows stop at c1
           const T* P = Y + (size_t)r0 * ldy + j;
           T* C = Y + (size_t)r0 * ldy + r0;
-          gemm<ROLE_TRAILING, false, 64, 64>(P, ldy, P, ldy, C, ldy, m_pad, m_pad - r0, nb, T(-1), T(1), 1, r0, r0, 0);
+          gemm<ROLE_TRAILING, false, 64, 64>(P, ldy, P, ldy, C, ldy, vrows, m_pad - r0, nb, T(-1), T(1), 1, r0, r0, 0, 0,
+                                             sc_, nullptr, 0, m_pad, c1);
         }
       }
-      const int col_end = step * nb;
-      const int width = col_end - col_begin;
-      // the last group has nothing left to overlap with: it runs on the main stream, on every CU
-      const bool overlap = pipe && step < nsteps;
-      hipStream_t ss = overlap ? stream_b : stream;       // solve pieces
-      hipStream_t sd = overlap ? stream_b : stream;       // downdate pieces follow their solve piece
-      if (!overlap && b_inflight) {                  // earlier pieces must be done before Sigma is touched again
+      const int width = c1 - c0;
+      // the last chunk has nothing left to overlap with: it runs on the main stream, on every CU
+      const bool overlap = (stream_b != nullptr) && (gi + 1 < nchunks);
+      hipStream_t ss = overlap ? stream_b : stream;
+      if (!overlap && b_inflight) {                  // earlier chunks must be done before W / Sigma are touched again
         HIPCHK(hipEventRecord(ev_b, stream_b));
         HIPCHK(hipStreamWaitEvent(stream, ev_b, 0));
         b_inflight = false;
       }
+      if (!overlap && c_inflight) {                  // ... and the chain itself
+        HIPCHK(hipEventRecord(ev_c, stream_c));
+        HIPCHK(hipStreamWaitEvent(stream, ev_c, 0));
+        c_inflight = false;
+      }
       if (overlap) {
         b_inflight = true;
-        HIPCHK(hipEventRecord(ev_chain[gi], stream));
+        HIPCHK(hipEventRecord(ev_chain[gi], sc_));
         HIPCHK(hipStreamWaitEvent(stream_b, ev_chain[gi], 0));
       }
       {
-        Scope sc(this, KID_SOLVE, ss);                    // column tiles [col_begin, col_end) of V, heaviest first
-        const int c0 = col_begin / tile, c1 = col_end / tile;
-        const int* list = d_tilemap + solve_off + 2 * (ntc - c1) * ntr;
-        gemm<ROLE_SOLVE, true>(d_W, ldy, Z, ldy, d_V, ldy, npad_live + nb, width, m_pad, T(1), T(0), 0, 0, 0, 1, 0,
-                               ss, list, (c1 - c0) * ntr);
+        Scope sc(this, KID_SOLVE, ss);                    // column tiles of the chunk, heaviest first
+        const int wt = width / tile;
+        const int* list = d_tilemap + solve_off + 2 * (ntc - wt) * ntr;
+        gemm<ROLE_SOLVE, true>(d_W + c0, ldy, Zs + c0, ldy, d_V + c0, ldy, npad_live + nb, width, width, T(1), T(0), 0, 0,
+                               0, 1, 0, ss, list, wt * ntr);
+      }
+      if (c1 < m_pad) {
+        Scope sc(this, KID_WUPDATE, ss);
+        gemm<ROLE_WUPDATE, false>(d_V + c0, ldy, Y + (size_t)c1 * ldy + c0, ldy, d_W + c1, ldy, npad_live + nb, m_pad - c1,
+                                  width, T(-1), T(1), 0, 0, 0, 0, 0, ss);
+      }
+      if (!overlap && nchunks > 1) {
+        // every column of V and y = L^-1 nu exist now: the state update runs beside the last downdate
+        HIPCHK(hipEventRecord(ev_chain[gi], stream));
+        HIPCHK(hipStreamWaitEvent(stream_b, ev_chain[gi], 0));
+        Scope sc(this, KID_STATE_UPDATE, stream_b);
+        k_state_update<T><<<(n + 3) / 4, 256, 0, stream_b>>>(mu(), d_V, ldy, n, d_V + (size_t)npad_live * ldy, m_pad);
+        b_inflight = true;
       }
       {
-        Scope sc(this, KID_DOWNDATE, sd);                 // Sigma -= V_g V_g^T (lower tiles + mirror)
-        gemm<ROLE_DOWNDATE, false>(d_V + col_begin, ldy, d_V + col_begin, ldy, S(), ld, npad_live, npad_live, width,
-                                   T(-1), T(1), 2, 0, 0, 0, 0, sd, d_tilemap, tri_count);
+        Scope sc(this, KID_DOWNDATE, ss);                 // Sigma -= V_g V_g^T (lower tiles + mirror)
+        gemm<ROLE_DOWNDATE, false>(d_V + c0, ldy, d_V + c0, ldy, S(), ld, npad_live, npad_live, width, T(-1), T(1), 2, 0,
+                                   0, 0, 0, ss, d_tilemap, tri_count);
       }
     }
     if (b_inflight) {
@@ -829,9 +902,11 @@ struct Filter : FilterBase {
       HIPCHK(hipStreamWaitEvent(stream, ev_b, 0));
       b_inflight = false;
     }
+    last_nchunks = nchunks;
+    for (int g = 0; g < nchunks; ++g) last_cend[g] = cend[g];
     const T* V = d_V;
     const T* yv = d_V + (size_t)npad_live * ldy;
-    {
+    if (nchunks == 1) {
       Scope sc(this, KID_STATE_UPDATE);
       k_state_update<T><<<(n + 3) / 4, 256, 0, stream>>>(mu(), V, ldy, n, yv, m_pad);
     }
@@ -878,16 +953,34 @@ struct Filter : FilterBase {
     const int m = last_m, nn = last_n, m_pad = last_m_pad;
     const int nb = NB();
     const int npad_live = round_up(nn, nb);
-    const size_t need = (size_t)npad_live * m_pad;
+    const size_t need = (size_t)npad_live * m_pad * 2;     // K and the scratch of the back-substitution
     if (need > K_elems) {
       if (d_K) HIPCHK(hipFree(d_K));
       d_K = nullptr;
       HIPCHK(hipMalloc(&d_K, need * sizeof(T)));
       K_elems = need;
     }
-    // K = V L^-1 = V Z^T: C[i][c] = sum_k V[i][k] Z[c][k]
-    const T* Z = d_Y + (size_t)m_pad * ldy;
-    gemm<ROLE_GAIN, false>(d_V, ldy, Z, ldy, d_K, m_pad, npad_live, m_pad, m_pad, T(1), T(0), 0, 0, 0, 0);
+    // K = V L^-1 by block back-substitution over the chunks of the factorisation (only the diagonal
+    // inverses Z_gg = L_gg^-T exist):  K_g = (V_g - K[:, c1:] L[c1:, c0:c1]) Z_gg^T,  last chunk first.
+    // One chunk: K = V Z^T.
+    const T* Zs = d_Y + (size_t)m_pad * ldy;
+    int wmax = 0;
+    for (int g = 0; g < last_nchunks; ++g) wmax = std::max(wmax, (last_cend[g] - (g ? last_cend[g - 1] : 0)) * nb);
+    T* Tm = d_K + (size_t)npad_live * m_pad;              // npad_live x wmax scratch behind K
+    for (int g = last_nchunks - 1; g >= 0; --g) {
+      const int c0 = (g ? last_cend[g - 1] : 0) * nb, c1 = last_cend[g] * nb, w = c1 - c0;
+      const T* A = d_V + c0;
+      int lda = ldy;
+      if (c1 < m_pad) {
+        dim3 grid((w + 255) / 256, npad_live);
+        k_copy2d<T><<<grid, 256, 0, stream>>>(d_V + c0, ldy, Tm, wmax, npad_live, w);
+        gemm<ROLE_GAIN, true>(d_K + c1, m_pad, d_Y + (size_t)c1 * ldy + c0, ldy, Tm, wmax, npad_live, w, m_pad - c1, T(-1),
+                              T(1), 0, 0, 0, 0);
+        A = Tm;
+        lda = wmax;
+      }
+      gemm<ROLE_GAIN, false>(A, lda, Zs + c0, ldy, d_K + c0, m_pad, npad_live, w, w, T(1), T(0), 0, 0, 0, 0);
+    }
     std::vector<T> tmp((size_t)nn * m);
     HIPCHK(hipMemcpy2DAsync(tmp.data(), (size_t)m * sizeof(T), d_K, (size_t)m_pad * sizeof(T), (size_t)m * sizeof(T), nn,
                             hipMemcpyDeviceToHost, stream));
@@ -1249,6 +1342,8 @@ struct Filter : FilterBase {
     }
     HIPCHK(hipGetLastError());
     last_m = sh_m; last_m_pad = m_pad; last_n = n;
+    last_nchunks = 1;
+    last_cend[0] = m_pad / nb;
     have_update = true;
     sh_stage = 0;
     return EKF_OK;

@@ -97,12 +97,28 @@ __global__ void k_sigma_ht(const T* __restrict__ S, int ld, int n,
 // features.  The 7 camera rows of W stay in registers across the features of the block.
 // blockIdx.y == gridDim.y-1 additionally writes the plane rows and the identity padding.
 // ---------------------------------------------------------------------------------------
+// Column chunks of the factorisation (see Filter::update): chunk g covers columns [end[g-1], end[g]).
+struct ChunkTab {
+  int n;
+  int end[8];
+};
+// Identity strip under S: chunk g keeps its own inverse Z_gg = L_gg^-T in rows [0, width_g) of the
+// strip, columns of the chunk: strip[i][c] = 1 where c - (first column of c's chunk) == i.
+__device__ __forceinline__ bool strip_is_one(const ChunkTab& t, int i, int c) {
+  int start = 0;
+#pragma unroll
+  for (int g = 0; g < 8; ++g)
+    if (g < t.n && c >= t.end[g]) start = t.end[g];
+  return c - start == i;
+}
+
 template <typename T, int KB>
 __global__ void k_innovation_cov(const T* __restrict__ W, int ldy,
                                  const T* __restrict__ Hc, const T* __restrict__ Hf,
                                  const int* __restrict__ pos, const int* __restrict__ coding,
                                  const int* __restrict__ midx, int M, int plane, T r_pix, T r_plane,
-                                 T* __restrict__ Sm, int m_pad, int k_begin, int k_end, T* __restrict__ Zid) {
+                                 T* __restrict__ Sm, int m_pad, int k_begin, int k_end, T* __restrict__ Zid,
+                                 ChunkTab tab = ChunkTab{0, {}}, int strip_rows = 0) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= m_pad) return;
   const int m = 2 * M + (plane ? 3 : 0);
@@ -128,9 +144,9 @@ __global__ void k_innovation_cov(const T* __restrict__ W, int ldy,
     if (c >= m) { a0 = T(0); a1 = T(0); }
     Sm[(size_t)(2 * k) * ldy + c] = a0;
     Sm[(size_t)(2 * k + 1) * ldy + c] = a1;
-    if (Zid) {                          // identity block under S (rows m_pad + r), same sweep
-      Zid[(size_t)(2 * k) * ldy + c] = (c == 2 * k) ? T(1) : T(0);
-      Zid[(size_t)(2 * k + 1) * ldy + c] = (c == 2 * k + 1) ? T(1) : T(0);
+    if (Zid && 2 * k < strip_rows) {    // identity strip under S (rows m_pad + i), same sweep
+      Zid[(size_t)(2 * k) * ldy + c] = strip_is_one(tab, 2 * k, c) ? T(1) : T(0);
+      Zid[(size_t)(2 * k + 1) * ldy + c] = strip_is_one(tab, 2 * k + 1, c) ? T(1) : T(0);
     }
   }
   if (blockIdx.y == gridDim.y - 1) {
@@ -144,7 +160,7 @@ __global__ void k_innovation_cov(const T* __restrict__ W, int ldy,
         v = T(1);                       // identity padding keeps the padded factorisation regular
       }
       Sm[(size_t)r * ldy + c] = v;
-      if (Zid) Zid[(size_t)r * ldy + c] = (c == r) ? T(1) : T(0);
+      if (Zid && r < strip_rows) Zid[(size_t)r * ldy + c] = strip_is_one(tab, r, c) ? T(1) : T(0);
     }
   }
 }
@@ -159,10 +175,12 @@ __global__ void k_innovation_cov(const T* __restrict__ W, int ldy,
 //   ktri: 1 = op(B) is upper-triangular in (k, j) (zero for k > j): the K loop of column tile
 //        bj stops at (bj + ktile_off + 1)*TS.
 // ROLE only tags the instantiation so that rocprofv3 lists each use of the tile kernel under
-// its own name (0 panel, 1 trailing, 2 downdate, 3 solve, 4 gain).
+// its own name (0 panel, 1 trailing, 2 downdate, 3 solve, 4 gain, 5 right-looking update of W).
+//   zrow / zcol_end: tiles whose first row is >= zrow (the inverse strip under S) stop at column
+//        zcol_end (the end of the current chunk); zrow = 0 disables the test.
 // Dimensions are multiples of the tile (K of the K-step): no guards.
 // ---------------------------------------------------------------------------------------
-enum : int { ROLE_PANEL = 0, ROLE_TRAILING = 1, ROLE_DOWNDATE = 2, ROLE_SOLVE = 3, ROLE_GAIN = 4 };
+enum : int { ROLE_PANEL = 0, ROLE_TRAILING = 1, ROLE_DOWNDATE = 2, ROLE_SOLVE = 3, ROLE_GAIN = 4, ROLE_WUPDATE = 5 };
 
 struct GemmArgs {
   const void* A; int lda;
@@ -176,6 +194,8 @@ struct GemmArgs {
   // solve) or in 8x8 super-tiles (downdate: the tiles in flight share their panels in L2), so
   // the makespan does not depend on how the dispatcher places workgroups.
   const int* tile_map; int ntiles; int* counter;
+  int zrow, zcol_end;
+  int stagger;                                  // persistent grid: the second half of the workgroups starts `stagger` x 3.4 us late
 };
 
 // Next tile of this workgroup: plain 2-D grid (one tile, then done) or the work queue.
@@ -213,6 +233,7 @@ __global__ void __launch_bounds__(256) k_gemm_valu(GemmArgs g) {
   while (gemm_next_tile(g, &s_tile, iter, bi, bj)) {
   const int grow0 = g.row_off + bi * TS, gcol0 = g.col_off + bj * TS;
   if (g.tri && grow0 + TS <= gcol0) continue;
+  if (g.zrow && grow0 >= g.zrow && gcol0 >= g.zcol_end) continue;
   const int K = g.ktri ? min(g.K, (bj + g.ktile_off + 1) * TS) : g.K;
   const int tx = tid & 15, ty = tid >> 4;
   const int lr = tid >> 2;            // 0..63 row within tile
@@ -298,10 +319,13 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(GemmArgs g) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   if (ROLE == ROLE_PANEL || ROLE == ROLE_TRAILING) __builtin_amdgcn_s_setprio(2);   // part of the serial chain
+  if (g.stagger && g.tile_map && blockIdx.x >= gridDim.x / 2)
+    for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   int bi, bj, iter = 0;
   while (gemm_next_tile(g, &s_tile, iter, bi, bj)) {
   const int grow0 = g.row_off + bi * TM, gcol0 = g.col_off + bj * TN;
   if (g.tri && grow0 + TM <= gcol0) continue;
+  if (g.zrow && grow0 >= g.zrow && gcol0 >= g.zcol_end) continue;
   const int K = g.ktri ? min(g.K, (bj + g.ktile_off + 1) * TN) : g.K;
   // A staging: TM*8 float4 per tile, PA per lane; 8 consecutive lanes cover 128 B of a row
   const float* Ag[PA];
@@ -393,14 +417,9 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(GemmArgs g) {
   __syncthreads();
   int stage = 0;
   for (int k0 = 0; k0 < K; k0 += BK, stage ^= 1) {
-    if (k0 + BK < K) {
-      store_tile(stage ^ 1);
-      if (k0 + 2 * BK < K) load_tile(k0 + 2 * BK);
-    }
     const f32x4* As = lds + stage * STAGE;
     const f32x4* Bs = As + NQ * TM;
-#pragma unroll
-    for (int s = 0; s < BK / 8; ++s) {
+    auto mfma_group = [&](int s) {
       const int q = 2 * s + h;
       f32x4 fa[MI], fb[NJ];
 #pragma unroll
@@ -420,7 +439,16 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(GemmArgs g) {
 #pragma unroll
           for (int j = 0; j < NJ; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    };
+    // the matrix pipe restarts right after the barrier; the staging of the next tile (other LDS stage, free
+    // since that barrier) and the global loads of the one after go out under the first MFMA group
+    mfma_group(0);
+    if (k0 + BK < K) {
+      store_tile(stage ^ 1);
+      if (k0 + 2 * BK < K) load_tile(k0 + 2 * BK);
     }
+#pragma unroll
+    for (int s = 1; s < BK / 8; ++s) mfma_group(s);
     __syncthreads();
   }
   // epilogue: acc reg e of lane -> row (e&3) + 8*(e>>2) + 4*h, col l31 of the 32x32 tile

@@ -41,6 +41,12 @@ int main() {
     float t2 = timeit<ROLE_DOWNDATE, false>(g, dim3(nt, 1), 10);
     double flop = (double)n * n * K;   // symmetric half
     printf("SYRK K=%4d  plain grid %.3f ms (%.1f TF)   tilemap %.3f ms (%.1f TF)\n", K, t1, flop / t1 / 1e9, t2, flop / t2 / 1e9);
+    for (int sg : {1, 2, 4, 8, 16}) {
+      g.stagger = sg;
+      float ts = timeit<ROLE_DOWNDATE, false>(g, dim3(nt, 1), 10);
+      printf("SYRK K=%4d  tilemap stagger %2d: %.3f ms (%.1f TF)\n", K, sg, ts, flop / ts / 1e9);
+    }
+    g.stagger = 0;
     g.tri = 1;
     float t4 = timeit<ROLE_DOWNDATE, false>(g, dim3(nt, 1), 10);
     printf("SYRK K=%4d  tilemap, no mirror %.3f ms (%.1f TF)\n", K, t4, flop / t4 / 1e9);
