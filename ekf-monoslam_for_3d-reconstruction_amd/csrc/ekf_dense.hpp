@@ -301,7 +301,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int ROLE, bool BT, int TM = 128, int TN = 128>
-__global__ void __launch_bounds__(256) k_gemm_mfma(GemmArgs g) {
+__global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmArgs g) {   // two workgroups per CU: <= 256 registers per lane
   // TM x TN output tile (64 or 128 each), 4 waves as 2 x 2, each wave (TM/2) x (TN/2) = MI x NJ
   // accumulators of 32x32.  The small shapes exist for the latency-bound launches (chain tiles, tail of
   // the triangular solve): same flop, 2-4x the workgroups.
@@ -409,47 +409,60 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(GemmArgs g) {
     }
   };
   // software pipeline: tile k computes from stage k&1 while tile k+1 is written to the other stage and
-  // tile k+2 is in flight from global memory; one barrier per K step
+  // tile k+2 is in flight from global memory; one barrier per K step.  The A / B fragments are double
+  // buffered too: the ds_reads of MFMA group g+1 go out before the 16 MFMAs of group g, and the first
+  // group of the NEXT stage is fetched right after the barrier, under the last group of this one, so the
+  // matrix pipe never waits for an LDS round trip.
+  constexpr int NG = BK / 8;                   // MFMA groups per K step (each: one b128 per fragment, 4 k-pairs)
+  static_assert(NG % 2 == 0, "fragment ping-pong assumes an even number of groups");
+  f32x4 fa[2][MI], fb[2][NJ];
+  auto read_frag = [&](int stage_, int s, int buf) {
+    const f32x4* As = lds + stage_ * STAGE;
+    const f32x4* Bs = As + NQ * TM;
+    const int q = 2 * s + h;
+#pragma unroll
+    for (int t = 0; t < MI; ++t) {
+      const int ar = wr * (TM / 2) + t * 32 + l31;
+      fa[buf][t] = As[q * TM + (ar ^ q)];
+    }
+#pragma unroll
+    for (int t = 0; t < NJ; ++t) {
+      const int br = wc * (TN / 2) + t * 32 + l31;
+      fb[buf][t] = Bs[q * TN + (br ^ q)];
+    }
+  };
+  auto mfma_group = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][i][e], fb[buf][j][e], acc[i][j], 0, 0, 0);
+  };
   __syncthreads();                             // the previous tile of this workgroup is done with the LDS
   load_tile(0);
   store_tile(0);
   if (BK < K) load_tile(BK);
   __syncthreads();
+  read_frag(0, 0, 0);
   int stage = 0;
   for (int k0 = 0; k0 < K; k0 += BK, stage ^= 1) {
-    const f32x4* As = lds + stage * STAGE;
-    const f32x4* Bs = As + NQ * TM;
-    auto mfma_group = [&](int s) {
-      const int q = 2 * s + h;
-      f32x4 fa[MI], fb[NJ];
+    const bool more = k0 + BK < K;
 #pragma unroll
-      for (int t = 0; t < MI; ++t) {
-        const int ar = wr * (TM / 2) + t * 32 + l31;
-        fa[t] = As[q * TM + (ar ^ q)];
+    for (int s = 0; s < NG; ++s) {
+      if (s + 1 < NG) {
+        read_frag(stage, s + 1, (s + 1) & 1);
+      } else {
+        __syncthreads();                       // stage^1 is complete, everybody has read this stage
+        if (more) read_frag(stage ^ 1, 0, 0);
       }
-#pragma unroll
-      for (int t = 0; t < NJ; ++t) {
-        const int br = wc * (TN / 2) + t * 32 + l31;
-        fb[t] = Bs[q * TN + (br ^ q)];
+      mfma_group(s & 1);
+      if (s == 0 && more) {
+        store_tile(stage ^ 1);
+        if (k0 + 2 * BK < K) load_tile(k0 + 2 * BK);
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
-    };
-    // the matrix pipe restarts right after the barrier; the staging of the next tile (other LDS stage, free
-    // since that barrier) and the global loads of the one after go out under the first MFMA group
-    mfma_group(0);
-    if (k0 + BK < K) {
-      store_tile(stage ^ 1);
-      if (k0 + 2 * BK < K) load_tile(k0 + 2 * BK);
     }
-#pragma unroll
-    for (int s = 1; s < BK / 8; ++s) mfma_group(s);
-    __syncthreads();
   }
   // epilogue: acc reg e of lane -> row (e&3) + 8*(e>>2) + 4*h, col l31 of the 32x32 tile
   const bool mirror = (TM == TN) && (g.tri == 2) && (grow0 >= gcol0 + TM);
