@@ -66,6 +66,11 @@ _PROTOS = {
     "ekf_update": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
     "ekf_update_device": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
     "ekf_rescue_high_innovation": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_double, _P]),
+    "ekf_set_frame": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int]),
+    "ekf_set_patch": (C.c_int, [_P, C.c_int, _P]),
+    "ekf_get_patch": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "ekf_get_blur_predictions": (C.c_int, [_P, _P]),
+    "ekf_find_matches": (C.c_int, [_P, C.c_double, _P, _P, _P]),
     "ekf_export_points": (C.c_int, [_P, _P, C.c_int]),
     "ekf_get_search_ellipses": (C.c_int, [_P, C.c_int, _P]),
     "ekf_ransac_1point": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, _P, _P, C.POINTER(C.c_int)]),

@@ -13,6 +13,7 @@
 
 #include "../../include/ekf_monoslam.h"
 #include "ekf_dense.hpp"
+#include "ekf_image.hpp"
 #include "ekf_kernels.hpp"
 
 namespace ekf {
@@ -85,6 +86,11 @@ struct FilterBase {
   virtual int rescue(const void*, const void*, const int*, int, double, unsigned char*) = 0;
   virtual int search_ellipses(int, int*) = 0;
   virtual int ransac(const void*, const int*, int, double, int*, unsigned char*, int*) = 0;
+  virtual int set_frame(const unsigned char*, int, int, int) = 0;
+  virtual int set_patch(int, const unsigned char*) = 0;
+  virtual int get_patch(int, int, unsigned char*) = 0;
+  virtual int blur_predictions(void*) = 0;
+  virtual int find_matches(double, void*, unsigned char*, float*) = 0;
   virtual int shard_configure(int, int) = 0;
   virtual int shard_view(ekf_shard_view*) = 0;
   virtual int shard_predict(const void*, const void*, int) = 0;
@@ -160,6 +166,18 @@ struct Filter : FilterBase {
   int opt_split16 = 8;
   int opt_chain_mask = 0;                               // 1: chain of chunks >= 1 on the reserved CUs only (measured slower: the trailing updates want more CUs)
   int last_nchunks = 1, last_cend[8] = {};
+  // image side (8f4): current frame, templates (original / matching), blur-pose predictions, match results
+  unsigned char* d_frame = nullptr;
+  size_t frame_cap = 0;
+  int frame_w = 0, frame_h = 0;
+  bool have_frame = false, have_blur = false;
+  unsigned char *d_patch[2] = {nullptr, nullptr}, *d_mpatch[2] = {nullptr, nullptr};
+  int cur_patch = 0;
+  T* d_hb = nullptr;
+  T* d_zm = nullptr;
+  unsigned char* d_found = nullptr;
+  float* d_score = nullptr;
+  int* d_keep = nullptr;
   int env_chunks[8] = {}, env_nchunks = 0;               // EKF_CHUNKS="5,10,14,16": tuning knob (block steps)
   int opt_pipeline = -1;                                 // -1 auto: on when the chain has >= 8 block steps
   int* d_tilemap = nullptr;                             // work lists: [lower-tri super-tiles | solve heavy-first]
@@ -187,7 +205,8 @@ struct Filter : FilterBase {
     for (auto e : pool) hipEventDestroy(e);
     void* ptrs[] = {d_pos, d_coding, d_mu[0], d_mu[1], d_S[0], d_S[1], d_scr, d_h, d_Hc, d_Hf, d_Sd,
                     d_flags, d_cflag, d_Jy, d_Yxyz, d_map_src, d_map_conv, d_Y, d_W, d_V, d_Dinv, d_z, d_midx,
-                    d_status, d_tmp, d_K, d_tilemap, d_counters, d_ibuf, d_rmask, d_pts};
+                    d_status, d_tmp, d_K, d_tilemap, d_counters, d_ibuf, d_rmask, d_pts,
+                    d_frame, d_patch[0], d_patch[1], d_mpatch[0], d_mpatch[1], d_hb, d_zm, d_found, d_score, d_keep};
     for (void* p : ptrs) if (p) hipFree(p);
     if (own_stream && stream) hipStreamDestroy(stream);
     if (stream_b) hipStreamDestroy(stream_b);
@@ -427,6 +446,13 @@ struct Filter : FilterBase {
       k_add_border<T><<<(n + 255) / 256, 256, 0, stream>>>(S(), ld, n, d_scr);
     }
     if (hipGetLastError() != hipSuccess) { err = "add_feature launch failed"; return -EKF_ERR_DEVICE; }
+    if (have_frame) {
+      // Patch::Patch(cv::Mat(frame, cv::Rect(pf.x - w/2, pf.y - w/2, w, w)), ...) (vR.cpp:318): float -> int truncation
+      const int w = cfg.window_size;
+      const int x0 = (int)(float(u) - float(w / 2)), y0 = (int)(float(v) - float(w / 2));
+      k_capture_patch<<<1, 256, 0, stream>>>(d_frame, frame_w, frame_h, x0, y0, w,
+                                            d_patch[cur_patch] + (size_t)N * w * w, d_mpatch[cur_patch] + (size_t)N * w * w);
+    }
     pos.push_back(n);
     coding.push_back(0);
     N += 1;
@@ -435,6 +461,107 @@ struct Filter : FilterBase {
     layout_dirty = true;
     have_meas = false;
     return 1;
+  }
+
+  // ---- image side: frame, templates, predicted blur, NCC search ---------------
+  int ensure_image_buffers() {
+    if (d_patch[0]) return EKF_OK;
+    const int w = cfg.window_size;
+    if (w < 1 || w > kMaxWindow) FAIL(EKF_ERR_UNSUPPORTED, "window_size outside [1, 32] for the device matcher");
+    const size_t bytes = (size_t)std::max(capN, 1) * w * w;
+    for (int b = 0; b < 2; ++b) {
+      HIPCHK(hipMalloc(&d_patch[b], bytes));
+      HIPCHK(hipMalloc(&d_mpatch[b], bytes));
+      HIPCHK(hipMemsetAsync(d_patch[b], 0, bytes, stream));
+      HIPCHK(hipMemsetAsync(d_mpatch[b], 0, bytes, stream));
+    }
+    HIPCHK(hipMalloc(&d_hb, (size_t)std::max(capN, 1) * 2 * sizeof(T)));
+    HIPCHK(hipMalloc(&d_zm, (size_t)std::max(capN, 1) * 2 * sizeof(T)));
+    HIPCHK(hipMalloc(&d_found, (size_t)std::max(capN, 1)));
+    HIPCHK(hipMalloc(&d_score, (size_t)std::max(capN, 1) * sizeof(float)));
+    HIPCHK(hipMalloc(&d_keep, (size_t)std::max(capN, 1) * sizeof(int)));
+    return EKF_OK;
+  }
+  int set_frame(const unsigned char* gray, int width, int height, int stride) override {
+    HIPCHK(hipSetDevice(device));
+    if (!gray || width <= 0 || height <= 0 || stride < width) FAIL(EKF_ERR_ARG, "bad frame");
+    if (width != cam.width || height != cam.height)
+      FAIL(EKF_ERR_ARG, "frame size differs from ekf_config image_width / image_height");
+    int rc = ensure_image_buffers();
+    if (rc) return rc;
+    const size_t need = (size_t)width * height;
+    if (need > frame_cap) {
+      if (d_frame) HIPCHK(hipFree(d_frame));
+      d_frame = nullptr;
+      HIPCHK(hipMalloc(&d_frame, need));
+      frame_cap = need;
+    }
+    HIPCHK(hipMemcpy2DAsync(d_frame, (size_t)width, gray, (size_t)stride, (size_t)width, height, hipMemcpyHostToDevice,
+                            stream));
+    HIPCHK(hipStreamSynchronize(stream));            // the caller's buffer may be reused at once
+    frame_w = width; frame_h = height;
+    have_frame = true;
+    return EKF_OK;
+  }
+  int set_patch(int index, const unsigned char* data) override {
+    HIPCHK(hipSetDevice(device));
+    if (index < 0 || index >= N || !data) FAIL(EKF_ERR_ARG, "feature index out of range");
+    int rc = ensure_image_buffers();
+    if (rc) return rc;
+    const size_t w2 = (size_t)cfg.window_size * cfg.window_size;
+    HIPCHK(hipMemcpyAsync(d_patch[cur_patch] + index * w2, data, w2, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(d_mpatch[cur_patch] + index * w2, data, w2, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return EKF_OK;
+  }
+  int get_patch(int index, int matching, unsigned char* out) override {
+    HIPCHK(hipSetDevice(device));
+    if (index < 0 || index >= N || !out) FAIL(EKF_ERR_ARG, "feature index out of range");
+    if (!d_patch[0]) FAIL(EKF_ERR_STATE, "no templates: call ekf_set_frame / ekf_set_patch first");
+    const size_t w2 = (size_t)cfg.window_size * cfg.window_size;
+    const unsigned char* src = (matching ? d_mpatch[cur_patch] : d_patch[cur_patch]) + index * w2;
+    HIPCHK(hipMemcpyAsync(out, src, w2, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return EKF_OK;
+  }
+  // predicted blur of every visible feature's template (inside predict(), vR.cpp:496-500, 546-548, 575-576)
+  int launch_blur() {
+    have_blur = false;
+    if (!d_patch[0] || N == 0) return EKF_OK;
+    Scope sc(this, KID_MISC);
+    k_blur_points<T><<<(N + 63) / 64, 64, 0, stream>>>(mu(), d_pos, d_coding, N, cam, T(cfg.T_camera), T(dT), d_hb);
+    k_blur_templates<T><<<N, 256, 0, stream>>>(d_h, d_hb, d_flags, cfg.window_size, cfg.kernel_size, d_patch[cur_patch],
+                                               d_mpatch[cur_patch]);
+    HIPCHK(hipGetLastError());
+    have_blur = true;
+    return EKF_OK;
+  }
+  int blur_predictions(void* out) override {
+    HIPCHK(hipSetDevice(device));
+    if (!have_blur) FAIL(EKF_ERR_STATE, "no blur predictions: ekf_predict with templates present computes them");
+    if (N) HIPCHK(hipMemcpyAsync(out, d_hb, (size_t)N * 2 * sizeof(T), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return EKF_OK;
+  }
+  int find_matches(double threshold, void* z, unsigned char* found, float* score) override {
+    HIPCHK(hipSetDevice(device));
+    if (!have_frame) FAIL(EKF_ERR_STATE, "ekf_find_matches needs ekf_set_frame");
+    if (!have_meas) FAIL(EKF_ERR_STATE, "ekf_find_matches needs the predictions of ekf_predict / ekf_measure");
+    if (N == 0) return EKF_OK;
+    int rc = ensure_sd();
+    if (rc) return rc;
+    {
+      Scope sc(this, KID_MISC);
+      k_ncc_search<T><<<N, 256, 0, stream>>>(d_frame, frame_w, frame_h, d_h, d_Sd, d_flags, cfg.window_size,
+                                             float(cfg.sigma_size), float(threshold), d_mpatch[cur_patch], d_zm, d_found,
+                                             d_score);
+    }
+    HIPCHK(hipGetLastError());
+    if (z) HIPCHK(hipMemcpyAsync(z, d_zm, (size_t)N * 2 * sizeof(T), hipMemcpyDeviceToHost, stream));
+    if (found) HIPCHK(hipMemcpyAsync(found, d_found, (size_t)N, hipMemcpyDeviceToHost, stream));
+    if (score) HIPCHK(hipMemcpyAsync(score, d_score, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return EKF_OK;
   }
 
   // zero everything of buffer `b` outside the live n x n (up to what was ever written there)
@@ -480,6 +607,18 @@ struct Filter : FilterBase {
                                                               d_Yxyz);
     }
     HIPCHK(hipGetLastError());
+    std::vector<int> keep;
+    if (d_patch[0]) {                            // the templates follow their features (patches.erase, vR.cpp:1298)
+      for (int i = 0; i < N; ++i)
+        if (!rm[i]) keep.push_back(i);
+      if (!keep.empty() && (int)keep.size() != N) {
+        const int w2 = cfg.window_size * cfg.window_size;
+        HIPCHK(hipMemcpyAsync(d_keep, keep.data(), keep.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        k_gather_patches<<<(int)keep.size(), 256, 0, stream>>>(d_patch[cur_patch], d_patch[1 - cur_patch], d_keep, w2);
+        k_gather_patches<<<(int)keep.size(), 256, 0, stream>>>(d_mpatch[cur_patch], d_mpatch[1 - cur_patch], d_keep, w2);
+        cur_patch = 1 - cur_patch;
+      }
+    }
     extent[dst] = std::max(extent[dst], n_new);
     int rc = zero_border(dst, n_new);
     if (rc) return rc;
@@ -568,7 +707,9 @@ struct Filter : FilterBase {
     }
     HIPCHK(hipGetLastError());
     have_update = false;
-    return launch_measure();
+    int rcm = launch_measure();
+    if (rcm) return rcm;
+    return launch_blur();
   }
 
   int measure() override {
@@ -1509,6 +1650,20 @@ int ekf_rescue_high_innovation(ekf_filter* f, const void* cam, const void* z, co
                                unsigned char* out) {
   IMPL_OR_ARG(f);
   return f->impl->rescue(cam, z, idx, M, thr, out);
+}
+int ekf_set_frame(ekf_filter* f, const unsigned char* gray, int width, int height, int stride) {
+  IMPL_OR_ARG(f);
+  return f->impl->set_frame(gray, width, height, stride);
+}
+int ekf_set_patch(ekf_filter* f, int index, const unsigned char* pixels) { IMPL_OR_ARG(f); return f->impl->set_patch(index, pixels); }
+int ekf_get_patch(ekf_filter* f, int index, int matching, unsigned char* out) {
+  IMPL_OR_ARG(f);
+  return f->impl->get_patch(index, matching, out);
+}
+int ekf_get_blur_predictions(ekf_filter* f, void* hb) { IMPL_OR_ARG(f); return f->impl->blur_predictions(hb); }
+int ekf_find_matches(ekf_filter* f, double threshold, void* z, unsigned char* found, float* score) {
+  IMPL_OR_ARG(f);
+  return f->impl->find_matches(threshold, z, found, score);
 }
 int ekf_export_points(ekf_filter* f, void* out, int conv) { IMPL_OR_ARG(f); if (!out) return EKF_ERR_ARG; return f->impl->export_points(out, conv); }
 int ekf_get_search_ellipses(ekf_filter* f, int sigma_size, int* out) { IMPL_OR_ARG(f); if (!out) return EKF_ERR_ARG; return f->impl->search_ellipses(sigma_size, out); }

@@ -193,6 +193,38 @@ class VSlamFilter:
                                                              idx.size, float(chi2_threshold), self._ptr(out)))
         return out.astype(bool)
 
+    # ---- image side (Patch.cpp / libblur.cpp) ---------------------------------------------------
+    def setFrame(self, gray):
+        """captureNewFrame's image after resize / grayscale: uint8 (height, width)."""
+        g = np.ascontiguousarray(gray, np.uint8)
+        if g.ndim != 2:
+            raise ValueError("frame must be a single-channel 8-bit image")
+        self._check(self._lib.ekf_set_frame(self._h, self._ptr(g), g.shape[1], g.shape[0], g.strides[0]))
+
+    def setPatch(self, index: int, pixels):
+        p = np.ascontiguousarray(pixels, np.uint8).reshape(-1)
+        self._check(self._lib.ekf_set_patch(self._h, int(index), self._ptr(p)))
+
+    def getPatch(self, index: int, matching: bool = False):
+        w = int(self._cfg.window_size)
+        out = np.zeros((w, w), np.uint8)
+        self._check(self._lib.ekf_get_patch(self._h, int(index), 1 if matching else 0, self._ptr(out)))
+        return out
+
+    def blurPredictions(self):
+        out = np.zeros((self.numOfFeatures(), 2), self.dtype)
+        self._check(self._lib.ekf_get_blur_predictions(self._h, self._ptr(out)))
+        return out
+
+    def findMatches(self, threshold: float = 0.8):
+        """Patch::findMatch for every visible feature: (z (N,2), found (N,) bool, score (N,) float32)."""
+        N = self.numOfFeatures()
+        z = np.zeros((N, 2), self.dtype)
+        found = np.zeros(N, np.uint8)
+        score = np.zeros(N, np.float32)
+        self._check(self._lib.ekf_find_matches(self._h, float(threshold), self._ptr(z), self._ptr(found), self._ptr(score)))
+        return z, found.astype(bool), score
+
     def getPointsFeatures(self, convert_inverse_depth: bool = False):
         """RosVSLAM::getPointsFeatures (RosVSLAMRansac.cpp:340-418): (N, 12) = xyz * map_scale + 3x3 covariance."""
         out = np.zeros((self.numOfFeatures(), 12), self.dtype)

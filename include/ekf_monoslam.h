@@ -160,6 +160,31 @@ int ekf_ransac_1point(ekf_filter* f, const void* z, const int* indices, int M, d
 int ekf_rescue_high_innovation(ekf_filter* f, const void* cam_before, const void* z, const int* indices,
                                int M, double chi2_threshold, unsigned char* is_hi);
 
+/* ---- image side: what sits between predict() and the EKF update in the reference ----
+ * captureNewFrame's image (vR.cpp:234-245) AFTER the node's resize / grayscale: 8-bit, single channel,
+ * image_width x image_height of the config; `stride` = bytes per row.  The frame is copied to the device.
+ * While a frame is set, ekf_add_feature also captures the feature's window_size^2 template at
+ * ((int)(u - w/2), (int)(v - w/2)) (Patch::Patch in addFeature, vR.cpp:318) and removals keep the
+ * templates aligned with their features (vR.cpp:1296-1299). */
+int ekf_set_frame(ekf_filter* f, const unsigned char* gray, int width, int height, int stride);
+/* Patch::patch of feature `index`: window_size^2 bytes, row-major (test injection / inspection).
+ * matching != 0 reads Patch::matching_patch (the blurred copy or the last matched window). */
+int ekf_set_patch(ekf_filter* f, int index, const unsigned char* pixels);
+int ekf_get_patch(ekf_filter* f, int index, int matching, unsigned char* out);
+/* hi_out_blurred of every feature (vR.cpp:546, 575): the prediction at the pose r + v T_camera dT,
+ * q (x) quat(w T_camera dT), 2 scalars per feature.  ekf_predict computes it, together with
+ * Patch::blur (Patch.cpp:50-57, libblur.cpp:17-79: line kernel, filter2D with BORDER_REFLECT_101) of every
+ * visible feature's template, whenever templates are present. */
+int ekf_get_blur_predictions(ekf_filter* f, void* hb);
+/* Patch::findMatch (Patch.cpp:215-293) for every visible feature, on the device: NCC
+ * (computeCorrelation, Patch.cpp:295-329) of the matching template against every window whose centre lies
+ * in the clamped sigma_size box and inside the Mahalanobis ellipse of the feature's 2x2 St block; first
+ * maximum in scan order; found[i] = (score >= threshold) (the reference's patch_matching_threshold is 0.8,
+ * Patch.cpp:14).  z: 2 scalars per feature (the matched centre, or -1 -1), score: the best NCC (-1 if no
+ * candidate).  A found feature's matching template becomes the matched window (Patch.cpp:286).
+ * Any of z / found / score may be NULL. */
+int ekf_find_matches(ekf_filter* f, double threshold, void* z, unsigned char* found, float* score);
+
 /* Full St for a measured set (vR.cpp:598): out is m x m column-major, m = 2M (+3). */
 int ekf_innovation_covariance(ekf_filter* f, const int* indices, int M, int plane_constraint,
                               void* S_out);

@@ -71,6 +71,23 @@ class VSlamFilterHip {
                                      hi.data()));
     return hi;
   }
+  // ---- image side: captureNewFrame's frame, Patch::findMatch for every visible feature -------------
+  // gray: 8-bit single-channel frame after the node's resize (image_width x image_height of the config)
+  void setFrame(const unsigned char* gray, int width, int height, int stride) {
+    check(ekf_set_frame(h_, gray, width, height, stride));
+  }
+  // z (2 per feature, -1 -1 when not found), found flags, NCC scores; threshold = patch_matching_threshold
+  void findMatches(std::vector<float>& z, std::vector<unsigned char>& found, std::vector<float>& score,
+                   double threshold = 0.8) {
+    const int N = numOfFeatures();
+    z.resize(2 * (size_t)N); found.resize(N); score.resize(N);
+    check(ekf_find_matches(h_, threshold, z.data(), found.data(), score.data()));
+  }
+  std::vector<unsigned char> patch(int index, bool matching = false, int window_size = 0) {
+    std::vector<unsigned char> p((size_t)window_size * window_size);
+    check(ekf_get_patch(h_, index, matching ? 1 : 0, p.data()));
+    return p;
+  }
   // drawPrediction's ellipse parameters (vR.cpp:1368-1382): 5 ints per feature
   std::vector<int> searchEllipses(int sigma_size) {
     std::vector<int> e(5 * (size_t)numOfFeatures());
