@@ -162,9 +162,10 @@ struct Filter : FilterBase {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipStream_t stream_b = nullptr, stream_c = nullptr;   // solve pieces / downdate pieces, overlapped with the chain
-  hipEvent_t ev_chain[8] = {}, ev_solve[8] = {}, ev_b = nullptr, ev_c = nullptr;
+  hipEvent_t ev_chain[8] = {}, ev_solve[8] = {}, ev_b = nullptr, ev_c = nullptr, ev_wu = nullptr;
   int opt_split16 = 8;
   int opt_chain_mask = 0;                               // 1: chain of chunks >= 1 on the reserved CUs only (measured slower: the trailing updates want more CUs)
+  int solve64_off = 0;
   int last_nchunks = 1, last_cend[8] = {};
   // image side (8f4): current frame, templates (original / matching), blur-pose predictions, match results
   unsigned char* d_frame = nullptr;
@@ -214,6 +215,7 @@ struct Filter : FilterBase {
     for (auto e : ev_chain) if (e) hipEventDestroy(e);
     for (auto e : ev_solve) if (e) hipEventDestroy(e);
     if (ev_b) hipEventDestroy(ev_b);
+    if (ev_wu) hipEventDestroy(ev_wu);
     if (ev_c) hipEventDestroy(ev_c);
   }
 
@@ -283,6 +285,7 @@ struct Filter : FilterBase {
     for (auto& e : ev_chain) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : ev_solve) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ev_b, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ev_wu, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ev_c, hipEventDisableTiming));
     const size_t sig = (size_t)n_pad * ld;
     HIPCHK(hipMalloc(&d_S[0], sig * sizeof(T)));
@@ -796,6 +799,9 @@ struct Filter : FilterBase {
     solve_off = (int)tm.size();
     for (int j = ntc - 1; j >= 0; --j)
       for (int i = 0; i < ntr; ++i) { tm.push_back(i); tm.push_back(j); }
+    solve64_off = (int)tm.size();                  // the same list for 64-row tiles (narrow chunks: more workgroups)
+    for (int j = ntc - 1; j >= 0; --j)
+      for (int i = 0; i < 2 * ntr; ++i) { tm.push_back(i); tm.push_back(j); }
     HIPCHK(hipStreamSynchronize(stream));
     HIPCHK(hipStreamSynchronize(stream_b));
     HIPCHK(hipStreamSynchronize(stream_c));
@@ -818,9 +824,9 @@ struct Filter : FilterBase {
       return env_nchunks;
     }
     if (opt_pipeline < 2) {
-      // default: three chunks ending at 1/4, 5/8 and 1 of the chain (tools/sweep_chunks.sh: the first chunk is
+      // default: three chunks ending at 4/16, 9/16 and 1 of the chain (tools/sweep_chunks.sh: the first chunk is
       // exposed, so it is short; every further chunk re-reads Sigma once in its downdate, so there are few)
-      static const int kEnd16[3] = {4, 10, 16};
+      static const int kEnd16[3] = {4, 9, 16};
       int k = 0, prev = 0;
       for (int g = 0; g < 3; ++g) {
         int e = (g == 2) ? nsteps : (nsteps * kEnd16[g] + 8) / 16;
@@ -997,11 +1003,8 @@ struct Filter : FilterBase {
       // the last chunk has nothing left to overlap with: it runs on the main stream, on every CU
       const bool overlap = (stream_b != nullptr) && (gi + 1 < nchunks);
       hipStream_t ss = overlap ? stream_b : stream;
-      if (!overlap && b_inflight) {                  // earlier chunks must be done before W / Sigma are touched again
-        HIPCHK(hipEventRecord(ev_b, stream_b));
-        HIPCHK(hipStreamWaitEvent(stream, ev_b, 0));
-        b_inflight = false;
-      }
+      if (!overlap && b_inflight)                    // the solve reads W: only the last W update has to be done
+        HIPCHK(hipStreamWaitEvent(stream, ev_wu, 0));
       if (!overlap && c_inflight) {                  // ... and the chain itself
         HIPCHK(hipEventRecord(ev_c, stream_c));
         HIPCHK(hipStreamWaitEvent(stream, ev_c, 0));
@@ -1015,14 +1018,32 @@ struct Filter : FilterBase {
       {
         Scope sc(this, KID_SOLVE, ss);                    // column tiles of the chunk, heaviest first
         const int wt = width / tile;
-        const int* list = d_tilemap + solve_off + 2 * (ntc - wt) * ntr;
-        gemm<ROLE_SOLVE, true>(d_W + c0, ldy, Zs + c0, ldy, d_V + c0, ldy, npad_live + nb, width, width, T(1), T(0), 0, 0,
-                               0, 1, 0, ss, list, wt * ntr);
+        const int slots = 2 * (overlap ? num_cus - reserved_cus : num_cus);
+        if (kIsF32 && opt_mfma && wt * ntr < slots) {     // narrow chunk: 64-row tiles fill the chip
+          const int* list = d_tilemap + solve64_off + 2 * (ntc - wt) * 2 * ntr;
+          gemm<ROLE_SOLVE, true, 64, 128>(d_W + c0, ldy, Zs + c0, ldy, d_V + c0, ldy, npad_live + nb, width, width, T(1),
+                                          T(0), 0, 0, 0, 1, 0, ss, list, wt * 2 * ntr);
+        } else {
+          const int* list = d_tilemap + solve_off + 2 * (ntc - wt) * ntr;
+          gemm<ROLE_SOLVE, true>(d_W + c0, ldy, Zs + c0, ldy, d_V + c0, ldy, npad_live + nb, width, width, T(1), T(0), 0,
+                                 0, 0, 1, 0, ss, list, wt * ntr);
+        }
       }
       if (c1 < m_pad) {
         Scope sc(this, KID_WUPDATE, ss);
-        gemm<ROLE_WUPDATE, false>(d_V + c0, ldy, Y + (size_t)c1 * ldy + c0, ldy, d_W + c1, ldy, npad_live + nb, m_pad - c1,
-                                  width, T(-1), T(1), 0, 0, 0, 0, 0, ss);
+        const int slots = 2 * (overlap ? num_cus - reserved_cus : num_cus);
+        if (kIsF32 && opt_mfma && ((m_pad - c1) / 128) * ntr < slots)
+          gemm<ROLE_WUPDATE, false, 64, 128>(d_V + c0, ldy, Y + (size_t)c1 * ldy + c0, ldy, d_W + c1, ldy, npad_live + nb,
+                                             m_pad - c1, width, T(-1), T(1), 0, 0, 0, 0, 0, ss);
+        else
+          gemm<ROLE_WUPDATE, false>(d_V + c0, ldy, Y + (size_t)c1 * ldy + c0, ldy, d_W + c1, ldy, npad_live + nb, m_pad - c1,
+                                    width, T(-1), T(1), 0, 0, 0, 0, 0, ss);
+      }
+      if (overlap && c1 < m_pad) HIPCHK(hipEventRecord(ev_wu, stream_b));
+      if (!overlap && b_inflight) {                  // earlier downdates must be done before Sigma is touched again
+        HIPCHK(hipEventRecord(ev_b, stream_b));
+        HIPCHK(hipStreamWaitEvent(stream, ev_b, 0));
+        b_inflight = false;
       }
       if (!overlap && nchunks > 1) {
         // every column of V and y = L^-1 nu exist now: the state update runs beside the last downdate

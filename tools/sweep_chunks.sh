@@ -1,19 +1,14 @@
 #!/bin/bash
-# throughput vs chunk pattern of the factorisation (EKF_CHUNKS = chunk ends in block steps, N = 1000: 16 steps),
-# chain-stream CU masking and the number of reserved CUs
+# throughput vs chunk pattern of the factorisation (EKF_CHUNKS = chunk ends in block steps, N = 1000: 16 steps)
 run() {
-  python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-propagate-pass 2>/dev/null > /tmp/sweep_c.json
+  python bench.py --steps 150 --warmup 5 --no-cpu-baseline --no-propagate-pass 2>/dev/null > /tmp/sweep_c.json
   python - "$1" <<'PY'
 import json, sys
 d = json.load(open("/tmp/sweep_c.json"))
 print(sys.argv[1], d["value"], d["ms_per_step"], d["run_sane"])
 PY
 }
-for mask in 1 0; do
-  for res in 16 32 48; do
-    for c in "8,16" "4,10,16" "4,8,12,16" "2,8,16" "3,8,13,16" "2,6,11,16"; do
-      export EKF_CHAIN_MASK=$mask EKF_RESERVED_CUS=$res EKF_CHUNKS=$c
-      run "mask $mask reserved $res chunks $c"
-    done
-  done
+for c in ${CHUNK_LIST:-"4,10,16" "4,10,14,16" "4,9,13,16" "3,8,13,16" "4,8,12,16" "4,10,13,16" "5,10,14,16" "4,9,14,16" "3,7,11,14,16" "4,8,12,14,16" "2,6,10,14,16"}; do
+  export EKF_CHUNKS=$c
+  run "chunks $c"
 done
