@@ -183,8 +183,9 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
     # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside bench.py)
     pmc_path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
     pmc = json.load(open(pmc_path))["kernels"] if (n_feat == 1000 and os.path.exists(pmc_path)) else {}
-    if roofline and "k_gemm_mfma<2, false>" in pmc:
-        roofline["traffic"] = pmc["k_gemm_mfma<2, false>"]["hbm_bytes_per_launch"]
+    dd_key = next((k for k in pmc if k.startswith("k_gemm_mfma<2, false")), None)     # ROLE 2 = downdate
+    if roofline and dd_key:
+        roofline["traffic"] = pmc[dd_key]["hbm_bytes_per_launch"]
         roofline["traffic_source"] = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2)"
     result = {
         "metric": "EKF updates/sec at N features (state dim 14+6N)",
