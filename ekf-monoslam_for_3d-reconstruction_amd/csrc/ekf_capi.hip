@@ -165,7 +165,7 @@ struct Filter : FilterBase {
   hipEvent_t ev_chain[8] = {}, ev_solve[8] = {}, ev_b = nullptr, ev_c = nullptr, ev_wu = nullptr;
   int opt_split16 = 8;
   int opt_chain_mask = 0;                               // 1: chain of chunks >= 1 on the reserved CUs only (measured slower: the trailing updates want more CUs)
-  int solve64_off = 0;
+  int solve64_off = 0, tri64_off = 0, tri64_count = 0;
   int last_nchunks = 1, last_cend[8] = {};
   // image side (8f4): current frame, templates (original / matching), blur-pose predictions, match results
   unsigned char* d_frame = nullptr;
@@ -802,6 +802,16 @@ struct Filter : FilterBase {
     solve64_off = (int)tm.size();                  // the same list for 64-row tiles (narrow chunks: more workgroups)
     for (int j = ntc - 1; j >= 0; --j)
       for (int i = 0; i < 2 * ntr; ++i) { tm.push_back(i); tm.push_back(j); }
+    tri64_off = (int)tm.size();                    // lower-triangular 64 x 64 tiles (small maps: 4x the workgroups)
+    {
+      const int nt64 = 2 * nt, ns64 = (nt64 + SB - 1) / SB;
+      for (int si = 0; si < ns64; ++si)
+        for (int sj = 0; sj <= si; ++sj)
+          for (int i = si * SB; i < std::min(nt64, (si + 1) * SB); ++i)
+            for (int j = sj * SB; j < std::min(nt64, (sj + 1) * SB); ++j)
+              if (j <= i) { tm.push_back(i); tm.push_back(j); }
+      tri64_count = ((int)tm.size() - tri64_off) / 2;
+    }
     HIPCHK(hipStreamSynchronize(stream));
     HIPCHK(hipStreamSynchronize(stream_b));
     HIPCHK(hipStreamSynchronize(stream_c));
@@ -1055,8 +1065,12 @@ struct Filter : FilterBase {
       }
       {
         Scope sc(this, KID_DOWNDATE, ss);                 // Sigma -= V_g V_g^T (lower tiles + mirror)
-        gemm<ROLE_DOWNDATE, false>(d_V + c0, ldy, d_V + c0, ldy, S(), ld, npad_live, npad_live, width, T(-1), T(1), 2, 0,
-                                   0, 0, 0, ss, d_tilemap, tri_count);
+        if (kIsF32 && opt_mfma && tri_count < num_cus)    // small map: 64 x 64 tiles, or most of the chip idles
+          gemm<ROLE_DOWNDATE, false, 64, 64>(d_V + c0, ldy, d_V + c0, ldy, S(), ld, npad_live, npad_live, width, T(-1), T(1),
+                                             2, 0, 0, 0, 0, ss, d_tilemap + tri64_off, tri64_count);
+        else
+          gemm<ROLE_DOWNDATE, false>(d_V + c0, ldy, d_V + c0, ldy, S(), ld, npad_live, npad_live, width, T(-1), T(1), 2, 0,
+                                     0, 0, 0, ss, d_tilemap, tri_count);
       }
     }
     if (b_inflight) {

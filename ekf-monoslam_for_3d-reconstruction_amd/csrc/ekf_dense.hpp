@@ -695,26 +695,26 @@ __device__ __forceinline__ void diag_factor16(float* a, int LDA, int K0, float* 
 #pragma unroll
   for (int j = 0; j < 16; ++j) r[j] = (j <= i) ? a[(K0 + i) * LDA + K0 + j] : 0.f;
   bool bad = false;
+  // X = L16^-1 is built in the same sweep (lane c holds column c: x[ii] = X[ii][c]): row ii of X only needs
+  // row ii of L (final once step ii-1 is done) and 1 / L[ii][ii], so its dot products fill the issue slots the
+  // dependent pivot -> rsq -> scale -> broadcast chain of the factorisation leaves empty.
+  float x[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     const float pk = lane_bcast(r[k], k);
     if (!(pk > 0.f)) bad = true;
     inv[k] = __frsqrt_rn(pk > 0.f ? pk : 1.f);
+    float acc = 0.f;                             // row k of X: -inv[k] * sum_{t<k} L[k][t] X[t][c]
+#pragma unroll
+    for (int t = 0; t < k; ++t) acc += lane_bcast(r[t], k) * x[t];
     const float lik = r[k] * inv[k];             // row k: pk * rsqrt(pk) = sqrt(pk)
     r[k] = lik;
 #pragma unroll
     for (int j = k + 1; j < 16; ++j) r[j] -= lik * lane_bcast(lik, j);
+    x[k] = (k == i) ? inv[k] : -inv[k] * acc;
+    if (k < i) x[k] = 0.f;
   }
   if (bad && lane == 0) status[0] = 1;
-  float x[16];                                   // X = L16^-1, lane c holds column c: x[i] = X[i][c]
-#pragma unroll
-  for (int ii = 0; ii < 16; ++ii) {
-    float acc = 0.f;
-#pragma unroll
-    for (int k = 0; k < ii; ++k) acc += lane_bcast(r[k], ii) * x[k];
-    x[ii] = (ii == i) ? inv[ii] : -inv[ii] * acc;
-    if (ii < i) x[ii] = 0.f;
-  }
   if (lane < 16) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
