@@ -133,8 +133,6 @@ def main():
 def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
     flt = build_filter(pkg, cfg, n_feat, px0)
     flt.set_option(3, args.pipeline)
-    if os.environ.get("EKF_SPLIT16"):
-        flt.set_option(4, int(os.environ["EKF_SPLIT16"]))
     n = flt.stateDim()
     d_z = torch.from_numpy(z.reshape(z.shape[0], -1)).to(dev).contiguous()
     d_idx = torch.arange(n_feat, dtype=torch.int32, device=dev)

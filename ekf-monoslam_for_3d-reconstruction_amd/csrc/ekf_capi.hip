@@ -163,7 +163,6 @@ struct Filter : FilterBase {
   bool own_stream = false;
   hipStream_t stream_b = nullptr, stream_c = nullptr;   // solve pieces / downdate pieces, overlapped with the chain
   hipEvent_t ev_chain[8] = {}, ev_solve[8] = {}, ev_b = nullptr, ev_c = nullptr, ev_wu = nullptr;
-  int opt_split16 = 8;
   int opt_chain_mask = 0;                               // 1: chain of chunks >= 1 on the reserved CUs only (measured slower: the trailing updates want more CUs)
   int solve64_off = 0, tri64_off = 0, tri64_count = 0;
   int last_nchunks = 1, last_cend[8] = {};
@@ -416,7 +415,6 @@ struct Filter : FilterBase {
       case EKF_OPT_USE_MFMA: opt_mfma = v ? 1 : 0; w_zeroed_n = -1; return EKF_OK;   // tile size changes the pads
       case EKF_OPT_PROFILE: resolve_profile(); opt_profile = v; return EKF_OK;
       case EKF_OPT_PIPELINE: opt_pipeline = (v < 0) ? -1 : v; return EKF_OK;
-      case 4: opt_split16 = std::max(1, std::min(15, v)); return EKF_OK;   // tuning knob: first group of a 2-group pipeline
       default: FAIL(EKF_ERR_ARG, "unknown option");
     }
   }

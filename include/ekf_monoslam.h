@@ -70,9 +70,10 @@ enum ekf_option {
   EKF_OPT_USE_MFMA = 1,
   /* profiling level: 0 off, 1 HIP events around the dominant kernels, 2 around every kernel. */
   EKF_OPT_PROFILE = 2,
-  /* 1: the solve / downdate contractions are cut into column groups and overlapped with the
-   * serial Cholesky chain on a second, CU-masked stream; 0: one stream, one launch each;
-   * -1 (default): on when the chain has at least 8 block steps (m >= 1024). */
+  /* Chunked factorisation: 0 = one chunk, one stream (plain blocked Cholesky + one solve + one downdate);
+   * 1 = the default three column chunks, the solve / W-update / downdate of every chunk but the last on a
+   * second, CU-masked stream beside the serial chain; k >= 2 = k equal chunks;
+   * -1 (default): as 1 when the chain has at least 8 block steps (m >= 1024), else as 0. */
   EKF_OPT_PIPELINE = 3
 };
 
