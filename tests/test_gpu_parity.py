@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import ekf_oracle as o
-from helpers import gpu_state, make_pair, relf
+from helpers import gpu_state, make_pair, oracle_cfg, relf
 
 pytestmark = pytest.mark.gpu
 
@@ -406,3 +406,68 @@ def test_two_stage_update_with_rescue(dtype):          # vR.cpp:964-1130, 1245-1
     mu, S = gpu_state(g)
     t = TOL[dtype]
     assert relf(mu, ref.mu) < t["mu"] * 10 and relf(S, ref.Sigma) < t["S"] * 2
+
+
+@pytest.mark.parametrize("dtype,mfma,chunks", [(np.float64, False, 3), (np.float32, True, 3), (np.float32, True, 2),
+                                              (np.float32, False, 4)])
+def test_chunked_pipeline_matches_oracle(dtype, mfma, chunks):
+    """The chunked factorisation on two streams (what N = 1000 runs by default), forced on a map small
+    enough for the oracle: diagonal-chunk inverses, right-looking W update, per-chunk downdates, and the
+    gain by back-substitution over the chunks."""
+    ref, g = make_pair(150, dtype, mfma=mfma)              # m = 300: 3 block steps (MFMA, 128) or 5 (64)
+    g.set_option(3, chunks)                                # EKF_OPT_PIPELINE = k chunks
+    vis, z = step(ref, g)
+    g.synchronize()
+    mu, S = gpu_state(g)
+    t = TOL[dtype]
+    assert relf(mu, ref.mu) < t["mu"] * 5
+    assert relf(S, ref.Sigma) < t["S"] * 2
+    assert np.abs(S - S.T).max() <= 1e-6 * np.abs(S).max()
+    K = g.getGain()
+    assert K.shape == ref.Kt.shape and relf(K, ref.Kt) < t["S"] * 50
+    # a second frame on the updated state, and agreement with the one-chunk path on the same inputs
+    g1 = make_pair(150, dtype, mfma=mfma)[1]
+    g1.set_option(3, 0)
+    ref2, _ = make_pair(150, dtype, mfma=mfma)
+    step(ref2, g1)
+    mu1, S1 = gpu_state(g1)
+    assert relf(mu1, mu) < t["mu"] * 5 and relf(S1, S) < t["S"]
+    vis, z = step(ref, g, seed=77)
+    mu, S = gpu_state(g)
+    assert relf(mu, ref.mu) < t["mu"] * 20 and relf(S, ref.Sigma) < t["S"] * 5
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_dynamic_resize_stream(dtype):
+    """BASELINE configs[4] at oracle size: a measurement stream with features removed and added every few
+    frames (vR.cpp:1296-1299 order: descending indices; additions land at the end), free-running on both
+    sides -- the state dimension, the layout and every buffer the step sizes from n change under way."""
+    ref, g = make_pair(60, dtype, capacity=80)
+    rng = np.random.default_rng(1236)                       # SURVEY 8d: add/delete schedule seed
+    cfg = oracle_cfg()
+    half = cfg.window_size // 2
+    t = TOL[dtype]
+    for frame in range(12):
+        ref.predict()
+        g.predict()
+        vis = ref.visible_indices()
+        z = o.synthetic_measurements(ref, vis, seed=2000 + frame, sigma=0.5)
+        ref.update(z, vis)
+        g.update(z, vis)
+        if frame % 3 == 2:
+            drop = sorted(rng.choice(len(ref.features), size=4, replace=False).tolist())
+            for i in reversed(drop):
+                ref.remove_feature(i)
+            g.removeFeatures(drop)
+            for _ in range(5):                               # one more than removed: the map also grows
+                u = float(rng.uniform(half + 1, cfg.image_width - half - 1))
+                v = float(rng.uniform(half + 1, cfg.image_height - half - 1))
+                assert ref.add_feature(u, v) == 1 and g.addFeature((u, v)) == 1
+            assert g.numOfFeatures() == len(ref.features) and g.stateDim() == ref.n
+            pos, cod = g.featureLayout()
+            assert list(pos) == [ft.position_in_state for ft in ref.features]
+        mu, S = gpu_state(g)
+        # free-running: rounding differences accumulate over the frames (fp32), none in fp64
+        assert relf(mu, ref.mu) < t["mu"] * (50 if dtype == np.float32 else 1e3), frame
+        assert relf(S, ref.Sigma) < t["S"] * (10 if dtype == np.float32 else 1e2), frame
+    assert g.numOfFeatures() == 64
