@@ -335,11 +335,22 @@ struct Filter : FilterBase {
       if (const char* e = getenv("EKF_RESERVED_CUS")) reserved_cus = std::max(1, std::min(num_cus / 2, atoi(e)));   // tuning knob
       std::vector<uint32_t> mask((num_cus + 31) / 32, 0xffffffffu);
       for (int i = 0; i < reserved_cus; ++i) mask[i / 32] &= ~(1u << (i % 32));
-      HIPCHK(hipExtStreamCreateWithCUMask(&stream_b, (uint32_t)mask.size(), mask.data()));
+      // (a runtime that refuses CU masks still gets a second stream: the overlap works, only less well)
+      if (hipExtStreamCreateWithCUMask(&stream_b, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        stream_b = nullptr;
+        reserved_cus = 0;
+        HIPCHK(hipStreamCreateWithFlags(&stream_b, hipStreamNonBlocking));
+      }
       // chain stream: ONLY the reserved CUs, so that a chain workgroup never lands next to tile-GEMM waves
       std::vector<uint32_t> cmask((num_cus + 31) / 32, 0u);
       for (int i = 0; i < reserved_cus; ++i) cmask[i / 32] |= (1u << (i % 32));
-      HIPCHK(hipExtStreamCreateWithCUMask(&stream_c, (uint32_t)cmask.size(), cmask.data()));
+      if (reserved_cus == 0 ||
+          hipExtStreamCreateWithCUMask(&stream_c, (uint32_t)cmask.size(), cmask.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        stream_c = nullptr;
+        HIPCHK(hipStreamCreateWithFlags(&stream_c, hipStreamNonBlocking));
+      }
       if (const char* e = getenv("EKF_CHAIN_MASK")) opt_chain_mask = atoi(e);
       if (const char* e = getenv("EKF_CHUNKS")) {           // tuning knob: chunk ends in block steps
         for (const char* q = e; *q && env_nchunks < 8;) {

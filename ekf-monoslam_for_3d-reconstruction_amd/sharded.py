@@ -198,6 +198,19 @@ def bench(pkg, cfg, n_feat, px0, z, args, rank, world, dev):
     k = min(5, args.steps)
     phase = {name: round(ms / k, 4) for name, (ms, cnt) in prof.items()}
     shard_ms = sum(phase.get(x, 0.0) for x in ("measure", "sigma_ht", "innovation_cov"))
+    # dominant kernel of a rank: its row panel of the downdate, (n / G) x n x m multiply-adds, every column
+    # (a panel cannot use the symmetry), timed with HIP events on the library's stream in the pass above
+    dd_ms, dd_cnt = prof.get("downdate_syrk", (0.0, 0))
+    roofline = None
+    if dd_cnt:
+        launches_per_step = dd_cnt / k
+        rows = n / world
+        flop = 2.0 * rows * n * (2 * n_feat) / max(1.0, round(launches_per_step))
+        ach = flop / (dd_ms / dd_cnt * 1e-3) / 1e12
+        roofline = {"kernel": "downdate row panel (k_gemm_nt_mfma, f32 MFMA 32x32x2), rank 0", "bound": "mfma",
+                    "achieved": round(ach, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4),
+                    "traffic": None, "avg_launch_ms": round(dd_ms / dd_cnt, 4),
+                    "algorithmic_flop_per_launch": flop, "launches_per_step": launches_per_step}
     result = {
         "metric": "EKF updates/sec at N features (state dim 14+6N)",
         "value": round(args.steps / elapsed, 2), "unit": "updates/s",
@@ -211,7 +224,7 @@ def bench(pkg, cfg, n_feat, px0, z, args, rank, world, dev):
         "run_sane": sane,
         "per_rank_kernel_ms": phase,
         "jacobian_innovation_shard_ms": round(shard_ms, 4),
-        "roofline": None, "cpu_baseline": None,
+        "roofline": roofline, "cpu_baseline": None,
     }
     flt.close()
     return result
