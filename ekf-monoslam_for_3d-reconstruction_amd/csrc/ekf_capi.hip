@@ -1464,41 +1464,75 @@ struct Filter : FilterBase {
     const int nb = NB();
     const int m_pad = sh_m_pad;
     const int npad_live = round_up(n, nb);
+    const int nsteps = m_pad / nb;
     T* Y = d_Y;
-    T* Z = d_Y + (size_t)m_pad * ldy;
+    T* Zs = d_Y + (size_t)m_pad * ldy;
+    // the chain is replicated on every rank (S is small); chunks of 4 block steps with diagonal-chunk
+    // inverses as in Filter::update, one stream: per chunk the rank solves and right-updates only ITS rows of
+    // [W; nu^T] (camera tile, own row panel, nu block)
+    ChunkTab tab{0, {}};
+    int cend[8];
+    {
+      const int want = std::min(8, (nsteps + 3) / 4);
+      int k = 0, prev = 0;
+      for (int g = 0; g < want; ++g) {
+        int e = (g + 1 == want) ? nsteps : std::min(nsteps, 4 * (g + 1));
+        if (e > prev) { cend[k++] = e; prev = e; }
+      }
+      tab.n = k;
+    }
+    int strip_rows = 0;
+    for (int g = 0; g < tab.n; ++g) {
+      tab.end[g] = cend[g] * nb;
+      strip_rows = std::max(strip_rows, (cend[g] - (g ? cend[g - 1] : 0)) * nb);
+    }
     { Scope sc(this, KID_MISC);
-      dim3 grid((m_pad + 255) / 256, m_pad);
-      k_set_identity<T><<<grid, 256, 0, stream>>>(Z, ldy, m_pad); }
-    for (int j = 0, step = 0; j < m_pad; j += nb, ++step) {
-      T* Ajj = Y + (size_t)j * ldy + j;
-      T* Dj = d_Dinv + (size_t)step * nb * nb;
-      { Scope sc(this, KID_CHOL_DIAG);
-        if (nb == 128) {
-          if constexpr (kIsF32) k_chol_diag_packed<><<<1, 512, 0, stream>>>(Ajj, ldy, Dj, d_status);
-        } else {
-          k_chol_diag<T, 64><<<1, 512, diag_lds(64), stream>>>(Ajj, ldy, Dj, d_status);
-        } }
-      const int r0 = j + nb;
-      { Scope sc(this, KID_CHOL_PANEL);
-        T* P = Y + (size_t)r0 * ldy + j;
-        gemm<ROLE_PANEL, false, 64, 128>(P, ldy, Dj, nb, P, ldy, m_pad, nb, nb, T(1), T(0), 0, 0, 0, 0); }
-      if (r0 < m_pad) {
-        Scope sc(this, KID_CHOL_TRAILING);
-        const T* P = Y + (size_t)r0 * ldy + j;
-        T* C = Y + (size_t)r0 * ldy + r0;
-        gemm<ROLE_TRAILING, false, 64, 64>(P, ldy, P, ldy, C, ldy, m_pad, m_pad - r0, nb, T(-1), T(1), 1, r0, r0, 0);
+      dim3 grid((m_pad + 255) / 256, strip_rows);
+      k_set_identity_strip<T><<<grid, 256, 0, stream>>>(Zs, ldy, m_pad, tab); }
+    struct Rows { int r0, count; };
+    const Rows ranges[3] = {{0, sh_p0 > 0 ? nb : 0}, {sh_p0, sh_prows}, {npad_live, nb}};
+    int step = 0;
+    for (int gi = 0; gi < tab.n; ++gi) {
+      const int c0 = step * nb, c1 = cend[gi] * nb, width = c1 - c0;
+      for (; step < cend[gi]; ++step) {
+        const int j = step * nb;
+        T* Ajj = Y + (size_t)j * ldy + j;
+        T* Dj = d_Dinv + (size_t)step * nb * nb;
+        { Scope sc(this, KID_CHOL_DIAG);
+          if (nb == 128) {
+            if constexpr (kIsF32) k_chol_diag_packed<><<<1, 512, 0, stream>>>(Ajj, ldy, Dj, d_status);
+          } else {
+            k_chol_diag<T, 64><<<1, 512, diag_lds(64), stream>>>(Ajj, ldy, Dj, d_status);
+          } }
+        const int r0 = j + nb;
+        const int vrows = m_pad - c0;
+        { Scope sc(this, KID_CHOL_PANEL);
+          T* P = Y + (size_t)r0 * ldy + j;
+          gemm<ROLE_PANEL, false, 64, 128>(P, ldy, Dj, nb, P, ldy, vrows, nb, nb, T(1), T(0), 0, 0, 0, 0); }
+        if (r0 < m_pad) {
+          Scope sc(this, KID_CHOL_TRAILING);
+          const T* P = Y + (size_t)r0 * ldy + j;
+          T* C = Y + (size_t)r0 * ldy + r0;
+          gemm<ROLE_TRAILING, false, 64, 64>(P, ldy, P, ldy, C, ldy, vrows, m_pad - r0, nb, T(-1), T(1), 1, r0, r0, 0, 0,
+                                             nullptr, nullptr, 0, m_pad, c1);
+        }
+      }
+      for (const Rows& rr : ranges) {
+        if (rr.count == 0) continue;
+        const size_t off = (size_t)rr.r0 * ldy;
+        { Scope sc(this, KID_SOLVE);
+          gemm<ROLE_SOLVE, true>(d_W + off + c0, ldy, Zs + c0, ldy, d_V + off + c0, ldy, rr.count, width, width, T(1), T(0),
+                                 0, 0, 0, 1); }
+        if (c1 < m_pad) {
+          Scope sc(this, KID_WUPDATE);
+          gemm<ROLE_WUPDATE, false>(d_V + off + c0, ldy, Y + (size_t)c1 * ldy + c0, ldy, d_W + off + c1, ldy, rr.count,
+                                    m_pad - c1, width, T(-1), T(1), 0, 0, 0, 0);
+        }
       }
     }
-    {
-      Scope sc(this, KID_SOLVE);
-      // camera tile (rows 0..nb-1; only rows < camera_dim are meaningful on this rank), own panel, nu block
-      if (sh_p0 > 0) gemm<ROLE_SOLVE, true>(d_W, ldy, Z, ldy, d_V, ldy, nb, m_pad, m_pad, T(1), T(0), 0, 0, 0, 1);
-      gemm<ROLE_SOLVE, true>(d_W + (size_t)sh_p0 * ldy, ldy, Z, ldy, d_V + (size_t)sh_p0 * ldy, ldy, sh_prows, m_pad,
-                             m_pad, T(1), T(0), 0, 0, 0, 1);
-      gemm<ROLE_SOLVE, true>(d_W + (size_t)npad_live * ldy, ldy, Z, ldy, d_V + (size_t)npad_live * ldy, ldy, nb, m_pad,
-                             m_pad, T(1), T(0), 0, 0, 0, 1);
-    }
     HIPCHK(hipGetLastError());
+    last_nchunks = tab.n;
+    for (int g = 0; g < tab.n; ++g) last_cend[g] = cend[g];
     sh_stage = 3;
     return EKF_OK;
   }
@@ -1527,8 +1561,6 @@ struct Filter : FilterBase {
     }
     HIPCHK(hipGetLastError());
     last_m = sh_m; last_m_pad = m_pad; last_n = n;
-    last_nchunks = 1;
-    last_cend[0] = m_pad / nb;
     have_update = true;
     sh_stage = 0;
     return EKF_OK;

@@ -493,12 +493,12 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmArgs g) {   // two wor
   }  // tile loop
 }
 
-// [S; I]: identity block under S for the factorisation that also yields L^-T.
+// Identity strip of the chunked factorisation (rows = widest chunk): see ChunkTab / strip_is_one.
 template <typename T>
-__global__ void k_set_identity(T* __restrict__ Z, int ldz, int m_pad) {
+__global__ void k_set_identity_strip(T* __restrict__ Z, int ldz, int m_pad, ChunkTab tab) {
   const int r = blockIdx.y;
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < m_pad; c += gridDim.x * blockDim.x)
-    Z[(size_t)r * ldz + c] = (r == c) ? T(1) : T(0);
+    Z[(size_t)r * ldz + c] = strip_is_one(tab, r, c) ? T(1) : T(0);
 }
 
 // ---------------------------------------------------------------------------------------
