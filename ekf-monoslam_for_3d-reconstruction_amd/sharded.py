@@ -129,8 +129,20 @@ class ShardedStep:
         self.rank, self.world = backend.rank, backend.world
         self.comm_s = 0.0
 
-    def _gather(self, t, start, count, timed):
+    def _gather(self, what, t, start, count):
+        """One all-gather; with `self.timing` set (a dict of event-pair lists) it is bracketed by events on
+        the current stream, the stream the phases and RCCL are ordered on."""
+        if self.timing is None:
+            all_gather_rows(t, start, count, self.rank, self.world)
+            return
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         all_gather_rows(t, start, count, self.rank, self.world)
+        e1.record()
+        self.timing.setdefault(what, []).append((e0, e1))
+
+    timing = None
 
     def step(self, z):
         """z: backend-specific handle of this frame's 2N measurements (device pointer for the HIP
@@ -140,11 +152,11 @@ class ShardedStep:
         b.predict()
         ts = b.tensors()
         for name in ("h", "Hc", "Hf", "flags"):                     # reassemble H
-            all_gather_rows(ts[name], 0, nf, self.rank, self.world)
+            self._gather("H", ts[name], 0, nf)
         b.innovation(z, b.N)
-        all_gather_rows(ts["S"], 0, 2 * nf, self.rank, self.world)   # reassemble S
+        self._gather("S", ts["S"], 0, 2 * nf)                        # reassemble S
         b.factor_solve()
-        all_gather_rows(ts["V"], b.camera_dim, b.rows_per_rank, self.rank, self.world)
+        self._gather("V", ts["V"], b.camera_dim, b.rows_per_rank)
         b.downdate()
 
 
@@ -191,11 +203,14 @@ def bench(pkg, cfg, n_feat, px0, z, args, rank, world, dev):
     # per-phase share of one step on this rank (HIP events around every kernel, separate short pass)
     flt.set_option(2, 2)
     flt.profile_reset()
+    stepper.timing = {}
     run(args.warmup, min(5, args.steps))
     torch.cuda.synchronize()
     prof = flt.profile()
     flt.set_option(2, 0)
     k = min(5, args.steps)
+    gather_ms = {what: round(sum(a.elapsed_time(b) for a, b in pairs) / k, 4) for what, pairs in stepper.timing.items()}
+    stepper.timing = None
     phase = {name: round(ms / k, 4) for name, (ms, cnt) in prof.items()}
     shard_ms = sum(phase.get(x, 0.0) for x in ("measure", "sigma_ht", "innovation_cov"))
     # dominant kernel of a rank: its row panel of the downdate, (n / G) x n x m multiply-adds, every column
@@ -224,6 +239,7 @@ def bench(pkg, cfg, n_feat, px0, z, args, rank, world, dev):
         "run_sane": sane,
         "per_rank_kernel_ms": phase,
         "jacobian_innovation_shard_ms": round(shard_ms, 4),
+        "allgather_ms_per_step": gather_ms,
         "roofline": roofline, "cpu_baseline": None,
     }
     flt.close()
