@@ -247,7 +247,15 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
                                      "avg_launch_ms": round(t_k * 1e3, 4),
                                      "algorithmic_bytes_per_launch": nbytes,
                                      "updates_per_s_with_streaming_propagate": round(args.steps / (t1 - t0), 2)}
-        ms, cnt = prof.get("propagate_strips", (0.0, 0))
+        # the default in-place strip kernel, timed in a short pass of its own (every-kernel events add launch gaps)
+        flt2.set_option(0, 0)
+        flt2.set_option(2, 2)
+        flt2.profile_reset()
+        for _ in range(20):
+            flt2.predict()
+        flt2.synchronize()
+        ms, cnt = flt2.profile().get("propagate_strips", (0.0, 0))
+        flt2.set_option(2, 0)
         if cnt:
             result["p_propagate_in_place"] = {"kernel": "k_strip_congruence<13>", "avg_launch_ms": round(ms / cnt, 4),
                                               "algorithmic_bytes_per_launch": 4.0 * 13 * n * 4}

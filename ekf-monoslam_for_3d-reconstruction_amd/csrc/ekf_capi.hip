@@ -222,7 +222,7 @@ struct Filter : FilterBase {
   bool prof_on(int kid) const {
     if (opt_profile >= 2) return true;
     if (opt_profile == 1)
-      return kid == KID_DOWNDATE || kid == KID_PROPAGATE_STREAMING || kid == KID_PROPAGATE_STRIPS;
+      return kid == KID_DOWNDATE || kid == KID_PROPAGATE_STREAMING;
     return false;
   }
   hipEvent_t get_event() {

@@ -68,7 +68,8 @@ enum ekf_option {
   EKF_OPT_PROPAGATE_STREAMING = 0,
   /* 1 (default): hand-written MFMA kernels for the dense contractions; 0: plain VALU tiles. */
   EKF_OPT_USE_MFMA = 1,
-  /* profiling level: 0 off, 1 HIP events around the dominant kernels, 2 around every kernel. */
+  /* profiling level: 0 off, 1 HIP events around the dominant kernels (downdate, streaming propagate),
+   * 2 around every kernel (each pair of events costs a few microseconds of launch gap). */
   EKF_OPT_PROFILE = 2,
   /* Chunked factorisation: 0 = one chunk, one stream (plain blocked Cholesky + one solve + one downdate);
    * 1 = the default three column chunks, the solve / W-update / downdate of every chunk but the last on a
