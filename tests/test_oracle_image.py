@@ -65,3 +65,19 @@ def test_find_match_recovers_a_known_shift():                  # Patch::findMatc
     # a prediction whose whole window is off the searchable area: no candidate at all
     found3, _, score3, _ = io_.find_match(moved, tpl, (3.0, 3.0), S, 2)
     assert not found3 and score3 == np.float32(-1)
+
+
+def test_image_oracle_reproduces_golden():
+    """tests/golden/image_w15.npz (make_golden_image.py): regression guard on the image oracle."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "image_w15.npz"))
+    frame, moved = g["frame"], g["moved"]
+    assert np.array_equal(io_.random_texture(96, 128, seed=31), frame)
+    for i in range(6):
+        tpl = io_.capture_patch(frame, g["centres"][i][0], g["centres"][i][1], 15)
+        assert np.array_equal(tpl, g["templates"][i])
+        assert np.array_equal(io_.matching_patch(tpl, g["blur_h"][i], g["blur_hb"][i], 2), g["blurred"][i])
+        ok, z, sc, _ = io_.find_match(moved, tpl, g["h_pred"][i], g["S"][i], 2)
+        assert ok == bool(g["found"][i]) and tuple(z) == tuple(g["z"][i]) and sc == g["score"][i]
+    assert np.array_equal(g["blurred"][0], g["templates"][0])            # motion shorter than kernel_size: a copy
+    assert not np.array_equal(g["blurred"][3], g["templates"][3])
