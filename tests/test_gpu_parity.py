@@ -504,3 +504,40 @@ def test_mid_size_chunked_equals_serial(n_feat, m_meas, plane):
     tol = 2e-4 if plane else 1e-5
     assert relf(mu_a, mu_b) < tol and relf(S_a, S_b) < 10 * tol
     assert np.abs(S_a - S_a.T).max() <= 1e-6 * np.abs(S_a).max()
+
+
+def test_largest_config_n4000_properties():
+    """BASELINE configs[4] size on one GPU (N = M = 4000, n = 24014, 63 block steps, 2 x 2.3 GB of Sigma):
+    one predict + update + a resize; the same size-independent properties as the N = 1000 test."""
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from ekf_monoslam_amd import synthetic
+    cfg = pkg.kinect_config()
+    N = 4000
+    px0, z = synthetic.measurement_stream(cfg, N, 2, sigma_px=0.5)
+    f = pkg.VSlamFilter(cfg, capacity_features=N)
+    f.setDt(1.0 / 30.0)
+    for (u, v) in px0:
+        assert f.addFeature((u, v)) == 1
+    with pytest.raises(Exception):
+        f.addFeature((100.0, 100.0))                        # capacity_features is a hard bound
+    assert f.numOfFeatures() == N and f.stateDim() == 14 + 6 * N
+    f.predict()
+    h, vis, rem, S2 = f.predictions()
+    assert vis.sum() >= 0.98 * N
+    d_pred = np.diag(f.getSigmaBlock(14, 14, 600, 600)).copy()
+    f.update(z[0].reshape(-1), np.arange(N, dtype=np.int32))
+    f.synchronize()                                         # raises if a Cholesky pivot was not positive
+    mu = f.getFullState()
+    assert np.all(np.isfinite(mu)) and abs(np.linalg.norm(mu[3:7]) - 1.0) < 1e-6
+    S = f.getSigmaBlock(0, 0, 620, 620)
+    assert np.abs(S - S.T).max() <= 1e-6 * np.abs(S).max()
+    d = np.diag(S)
+    assert np.all(d > 0) and np.all(d[14:614] <= d_pred * (1 + 1e-5))
+    far = f.getSigmaBlock(24014 - 300, 0, 300, 300)          # a block far from the diagonal against its mirror
+    assert relf(far, f.getSigmaBlock(0, 24014 - 300, 300, 300).T) < 1e-6
+    f.removeFeatures([5, 1999, 3999])                        # one compaction pass over 2.3 GB
+    assert f.numOfFeatures() == N - 3 and f.stateDim() == 14 + 6 * (N - 3)
+    f.predict()
+    h, vis, rem, S2 = f.predictions()
+    assert np.all(np.isfinite(h)) and vis.sum() >= 0.98 * (N - 3)
