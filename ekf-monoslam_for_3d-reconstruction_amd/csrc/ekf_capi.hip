@@ -996,7 +996,7 @@ struct Filter : FilterBase {
           Scope sc(this, KID_CHOL_DIAG, sc_);
           if (nb == 128) {
             if constexpr (kIsF32)
-              k_chol_diag_packed<><<<1, 512, 0, sc_>>>(Ajj, ldy, Dj, d_status);
+              k_chol_diag_packed<><<<1, 512, 0, sc_>>>(Ajj, ldy, Dj, d_status, std::max(1, std::min(8, (m - j + 15) / 16)));
           } else {
             k_chol_diag<T, 64><<<1, 512, diag_lds(64), sc_>>>(Ajj, ldy, Dj, d_status);
           }
@@ -1500,7 +1500,8 @@ struct Filter : FilterBase {
         T* Dj = d_Dinv + (size_t)step * nb * nb;
         { Scope sc(this, KID_CHOL_DIAG);
           if (nb == 128) {
-            if constexpr (kIsF32) k_chol_diag_packed<><<<1, 512, 0, stream>>>(Ajj, ldy, Dj, d_status);
+            if constexpr (kIsF32)
+              k_chol_diag_packed<><<<1, 512, 0, stream>>>(Ajj, ldy, Dj, d_status, std::max(1, std::min(8, (sh_m - j + 15) / 16)));
           } else {
             k_chol_diag<T, 64><<<1, 512, diag_lds(64), stream>>>(Ajj, ldy, Dj, d_status);
           } }

@@ -728,7 +728,10 @@ __device__ __forceinline__ void diag_factor16(float* a, int LDA, int K0, float* 
 
 template <int MASK = 7>
 __global__ void __launch_bounds__(512)
-k_chol_diag_packed(float* __restrict__ Aglob, int ld, float* __restrict__ Dinv, int* __restrict__ status) {
+k_chol_diag_packed(float* __restrict__ Aglob, int ld, float* __restrict__ Dinv, int* __restrict__ status,
+                   int nblk_real = 8) {
+  // nblk_real: 16-column blocks that hold real rows of S; the rest of the 128 block is the identity padding of
+  // the last step (L = Z = I there, decoupled from the real part) and is written back untouched.
   constexpr int NB = 128, LDA = NB + 1, NT = 512, NBLK = NB / 16;
   typedef float f4 __attribute__((ext_vector_type(4)));
   __shared__ float a[NB * LDA];
@@ -776,7 +779,7 @@ k_chol_diag_packed(float* __restrict__ Aglob, int ld, float* __restrict__ Dinv, 
       for (int e = 0; e < 4; ++e) a[(prow0 + 4 * lq + e) * LDA + K0 + lr] = acc[e];
     }
     __syncthreads();
-    if (nbelow == 0) break;
+    if (nbelow == 0 || b + 1 >= nblk_real) break;
     // (3a) urgent tiles: block column b+1 (what the next 16x16 factor and the next panel read): the
     // nbelow tiles below/at the diagonal + the Z tiles of row blocks 0..b: always NBLK tiles, one per wave
     if (MASK & 4) {
