@@ -164,7 +164,7 @@ struct Filter : FilterBase {
   hipStream_t stream_b = nullptr, stream_c = nullptr;   // solve pieces / downdate pieces, overlapped with the chain
   hipEvent_t ev_chain[8] = {}, ev_solve[8] = {}, ev_b = nullptr, ev_c = nullptr, ev_wu = nullptr;
   int opt_chain_mask = 0;                               // 1: chain of chunks >= 1 on the reserved CUs only (measured slower: the trailing updates want more CUs)
-  int solve64_off = 0, tri64_off = 0, tri64_count = 0;
+  int solve64_off = 0, solve6464_off = 0, tri64_off = 0, tri64_count = 0;
   int last_nchunks = 1, last_cend[8] = {};
   // image side (8f4): current frame, templates (original / matching), blur-pose predictions, match results
   unsigned char* d_frame = nullptr;
@@ -811,6 +811,9 @@ struct Filter : FilterBase {
     solve64_off = (int)tm.size();                  // the same list for 64-row tiles (narrow chunks: more workgroups)
     for (int j = ntc - 1; j >= 0; --j)
       for (int i = 0; i < 2 * ntr; ++i) { tm.push_back(i); tm.push_back(j); }
+    solve6464_off = (int)tm.size();                // ... and for 64 x 64 tiles (small maps)
+    for (int j = 2 * ntc - 1; j >= 0; --j)
+      for (int i = 0; i < 2 * ntr; ++i) { tm.push_back(i); tm.push_back(j); }
     tri64_off = (int)tm.size();                    // lower-triangular 64 x 64 tiles (small maps: 4x the workgroups)
     {
       const int nt64 = 2 * nt, ns64 = (nt64 + SB - 1) / SB;
@@ -1038,7 +1041,11 @@ struct Filter : FilterBase {
         Scope sc(this, KID_SOLVE, ss);                    // column tiles of the chunk, heaviest first
         const int wt = width / tile;
         const int slots = 2 * (overlap ? num_cus - reserved_cus : num_cus);
-        if (kIsF32 && opt_mfma && wt * ntr < slots) {     // narrow chunk: 64-row tiles fill the chip
+        if (kIsF32 && opt_mfma && 4 * wt * ntr < slots) { // small map: 64 x 64 tiles
+          const int* list = d_tilemap + solve6464_off + 2 * (2 * ntc - 2 * wt) * 2 * ntr;
+          gemm<ROLE_SOLVE, true, 64, 64>(d_W + c0, ldy, Zs + c0, ldy, d_V + c0, ldy, npad_live + nb, width, width, T(1),
+                                         T(0), 0, 0, 0, 1, 0, ss, list, 2 * wt * 2 * ntr);
+        } else if (kIsF32 && opt_mfma && wt * ntr < slots) {     // narrow chunk: 64-row tiles fill the chip
           const int* list = d_tilemap + solve64_off + 2 * (ntc - wt) * 2 * ntr;
           gemm<ROLE_SOLVE, true, 64, 128>(d_W + c0, ldy, Zs + c0, ldy, d_V + c0, ldy, npad_live + nb, width, width, T(1),
                                           T(0), 0, 0, 0, 1, 0, ss, list, wt * 2 * ntr);
