@@ -910,12 +910,12 @@ struct Filter : FilterBase {
       const ChunkTab ct = tab ? *tab : ChunkTab{0, {}};
       if (small) {
         constexpr int KB = 1;
-        dim3 grid((m_pad + 255) / 256, std::max(1, (M + KB - 1) / KB));
+        dim3 grid((m_pad + 255) / 256, std::max(1, (M + KB - 1) / KB) + (m_pad - 2 * M + 7) / 8);
         k_innovation_cov<T, KB><<<grid, 256, 0, stream>>>(d_W, ldy, d_Hc, d_Hf, d_pos, d_coding, ip, M, plane,
                                                         T(sigma_pixel_2), T(0.00001), d_Y, m_pad, 0, M, zid, ct, strip_rows);
       } else {
         constexpr int KB = 8;
-        dim3 grid((m_pad + 255) / 256, std::max(1, (M + KB - 1) / KB));
+        dim3 grid((m_pad + 255) / 256, std::max(1, (M + KB - 1) / KB) + (m_pad - 2 * M + 7) / 8);
         k_innovation_cov<T, KB><<<grid, 256, 0, stream>>>(d_W, ldy, d_Hc, d_Hf, d_pos, d_coding, ip, M, plane,
                                                         T(sigma_pixel_2), T(0.00001), d_Y, m_pad, 0, M, zid, ct, strip_rows);
       }
@@ -1455,7 +1455,7 @@ struct Filter : FilterBase {
     {
       Scope sc(this, KID_INNOVATION_COV);
       constexpr int KB = 8;
-      dim3 grid((m_pad + 255) / 256, std::max(1, (sh_f1 - sh_f0 + KB - 1) / KB));
+      dim3 grid((m_pad + 255) / 256, std::max(1, (sh_f1 - sh_f0 + KB - 1) / KB) + (m_pad - 2 * M + 7) / 8);
       k_innovation_cov<T, KB><<<grid, 256, 0, stream>>>(d_W, ldy, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane,
                                                       T(sigma_pixel_2), T(0.00001), d_Y, m_pad, sh_f0, sh_f1,
                                                       static_cast<T*>(nullptr));

@@ -95,7 +95,7 @@ __global__ void k_sigma_ht(const T* __restrict__ S, int ld, int n,
 // ---------------------------------------------------------------------------------------
 // S = H W + R.  Lane = column c of S (coalesced along W rows); a block handles KB measured
 // features.  The 7 camera rows of W stay in registers across the features of the block.
-// blockIdx.y == gridDim.y-1 additionally writes the plane rows and the identity padding.
+// Blocks past the feature blocks write the plane rows and the identity padding, 8 rows each.
 // ---------------------------------------------------------------------------------------
 // Column chunks of the factorisation (see Filter::update): chunk g covers columns [end[g-1], end[g]).
 struct ChunkTab {
@@ -125,7 +125,10 @@ __global__ void k_innovation_cov(const T* __restrict__ W, int ldy,
   T wc[7];
 #pragma unroll
   for (int t = 0; t < 7; ++t) wc[t] = W[(size_t)t * ldy + c];
+  // blockIdx.y < nfb: KB measured features each; the blocks after them: 8 rows each of the plane / padding rows
+  const int nfb = max(1, (k_end - k_begin + KB - 1) / KB);
   const int k0 = k_begin + blockIdx.y * KB;               // measured features [k_begin, k_end)
+  if (blockIdx.y < nfb)
   for (int k = k0; k < min(k0 + KB, k_end); ++k) {
     const int fi = midx[k];
     const int p = pos[fi];
@@ -149,8 +152,9 @@ __global__ void k_innovation_cov(const T* __restrict__ W, int ldy,
       Zid[(size_t)(2 * k + 1) * ldy + c] = strip_is_one(tab, 2 * k + 1, c) ? T(1) : T(0);
     }
   }
-  if (blockIdx.y == gridDim.y - 1) {
-    for (int r = 2 * M; r < m_pad; ++r) {
+  if (blockIdx.y >= nfb) {
+    const int rb = 2 * M + (blockIdx.y - nfb) * 8;
+    for (int r = rb; r < min(rb + 8, m_pad); ++r) {
       T v = T(0);
       if (r < m) {                      // plane rows: H = e1, e4, e6  -> rows 1, 4, 6 of W
         const int e = r - 2 * M;
