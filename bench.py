@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--no-propagate-pass", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--pipeline", type=int, default=-1, help="EKF_OPT_PIPELINE (overlap chain with solve/downdate pieces)")
+    ap.add_argument("--split-bf16", action="store_true",
+                    help="EKF_OPT_SPLIT_BF16: downdate on the bf16 matrix pipe, fp32 operands split 3 x bf16 (NOT the default "
+                         "and not the headline: the line then says so in `dtype` and `config`)")
     return ap.parse_args()
 
 
@@ -133,6 +136,8 @@ def main():
 def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
     flt = build_filter(pkg, cfg, n_feat, px0)
     flt.set_option(3, args.pipeline)
+    if args.split_bf16:
+        flt.set_option(4, 1)
     n = flt.stateDim()
     d_z = torch.from_numpy(z.reshape(z.shape[0], -1)).to(dev).contiguous()
     d_idx = torch.arange(n_feat, dtype=torch.int32, device=dev)
@@ -190,7 +195,8 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
         "value": round(args.steps / elapsed, 2), "unit": "updates/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32 (downdate: 3 x bf16 split operands, f32 accumulate)" if args.split_bf16 else "f32",
+        "data": "synthetic",
         "config": {"workload": f"N={n_feat} inverse-depth features, n={n}, M=N measured per frame, "
                                f"fp32, 1xMI355X (BASELINE configs[{2 if n_feat == 1000 else 1}])",
                    "features": n_feat, "state_dim": n, "measured_per_frame": n_feat,

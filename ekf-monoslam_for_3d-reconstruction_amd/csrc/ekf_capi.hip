@@ -14,6 +14,7 @@
 #include "../../include/ekf_monoslam.h"
 #include "ekf_dense.hpp"
 #include "ekf_image.hpp"
+#include "ekf_split.hpp"
 #include "ekf_kernels.hpp"
 
 namespace ekf {
@@ -165,6 +166,8 @@ struct Filter : FilterBase {
   hipEvent_t ev_chain[8] = {}, ev_solve[8] = {}, ev_b = nullptr, ev_c = nullptr, ev_wu = nullptr;
   int opt_chain_mask = 0;                               // 1: chain of chunks >= 1 on the reserved CUs only (measured slower: the trailing updates want more CUs)
   int solve64_off = 0, solve6464_off = 0, tri64_off = 0, tri64_count = 0;
+  int opt_split_bf16 = 0;                               // EKF_OPT_SPLIT_BF16: downdate on the bf16 matrix pipe, 3 x bf16 per operand
+  __bf16* d_Vs[3] = {nullptr, nullptr, nullptr};
   int last_nchunks = 1, last_cend[8] = {};
   // image side (8f4): current frame, templates (original / matching), blur-pose predictions, match results
   unsigned char* d_frame = nullptr;
@@ -206,7 +209,8 @@ struct Filter : FilterBase {
     void* ptrs[] = {d_pos, d_coding, d_mu[0], d_mu[1], d_S[0], d_S[1], d_scr, d_h, d_Hc, d_Hf, d_Sd,
                     d_flags, d_cflag, d_Jy, d_Yxyz, d_map_src, d_map_conv, d_Y, d_W, d_V, d_Dinv, d_z, d_midx,
                     d_status, d_tmp, d_K, d_tilemap, d_counters, d_ibuf, d_rmask, d_pts,
-                    d_frame, d_patch[0], d_patch[1], d_mpatch[0], d_mpatch[1], d_hb, d_zm, d_found, d_score, d_keep};
+                    d_frame, d_patch[0], d_patch[1], d_mpatch[0], d_mpatch[1], d_hb, d_zm, d_found, d_score, d_keep,
+                    d_Vs[0], d_Vs[1], d_Vs[2]};
     for (void* p : ptrs) if (p) hipFree(p);
     if (own_stream && stream) hipStreamDestroy(stream);
     if (stream_b) hipStreamDestroy(stream_b);
@@ -426,6 +430,7 @@ struct Filter : FilterBase {
       case EKF_OPT_USE_MFMA: opt_mfma = v ? 1 : 0; w_zeroed_n = -1; return EKF_OK;   // tile size changes the pads
       case EKF_OPT_PROFILE: resolve_profile(); opt_profile = v; return EKF_OK;
       case EKF_OPT_PIPELINE: opt_pipeline = (v < 0) ? -1 : v; return EKF_OK;
+      case EKF_OPT_SPLIT_BF16: opt_split_bf16 = v ? 1 : 0; return EKF_OK;
       default: FAIL(EKF_ERR_ARG, "unknown option");
     }
   }
@@ -1079,7 +1084,27 @@ struct Filter : FilterBase {
         k_state_update<T><<<(n + 3) / 4, 256, 0, stream_b>>>(mu(), d_V, ldy, n, d_V + (size_t)npad_live * ldy, m_pad);
         b_inflight = true;
       }
-      {
+      bool split_done = false;
+      if constexpr (kIsF32) {
+        if (opt_split_bf16 && opt_mfma && tri_count >= num_cus && counter_next < 64) {
+          // opt-in: the same contraction on the bf16 matrix pipe, V_g split into three bf16 planes (ekf_split.hpp)
+          const size_t plane_elems = (size_t)(n_pad + 128) * ldy;
+          for (auto& pp : d_Vs)
+            if (!pp) HIPCHK(hipMalloc(&pp, plane_elems * sizeof(__bf16)));
+          {
+            Scope sc(this, KID_MISC, ss);
+            dim3 grid((width + 255) / 256, npad_live);
+            k_split_bf16<<<grid, 256, 0, ss>>>(d_V, ldy, npad_live, c0, width, d_Vs[0], d_Vs[1], d_Vs[2]);
+          }
+          Scope sc(this, KID_DOWNDATE, ss);
+          SplitArgs a{{d_Vs[0] + c0, d_Vs[1] + c0, d_Vs[2] + c0}, ldy, S(), ld, width, d_tilemap, tri_count,
+                      d_counters + counter_next++};
+          const int wgs = 2 * (overlap ? (num_cus - reserved_cus) : num_cus);
+          k_syrk_bf16x3<<<std::min(tri_count, wgs), 256, 0, ss>>>(a);
+          split_done = true;
+        }
+      }
+      if (!split_done) {
         Scope sc(this, KID_DOWNDATE, ss);                 // Sigma -= V_g V_g^T (lower tiles + mirror)
         if (kIsF32 && opt_mfma && tri_count < num_cus)    // small map: 64 x 64 tiles, or most of the chip idles
           gemm<ROLE_DOWNDATE, false, 64, 64>(d_V + c0, ldy, d_V + c0, ldy, S(), ld, npad_live, npad_live, width, T(-1), T(1),

@@ -75,7 +75,12 @@ enum ekf_option {
    * 1 = the default three column chunks, the solve / W-update / downdate of every chunk but the last on a
    * second, CU-masked stream beside the serial chain; k >= 2 = k equal chunks;
    * -1 (default): as 1 when the chain has at least 8 block steps (m >= 1024), else as 0. */
-  EKF_OPT_PIPELINE = 3
+  EKF_OPT_PIPELINE = 3,
+  /* 0 (default): every contraction in exact fp32 (v_mfma_f32_32x32x2_f32).  1: the covariance downdate of large
+   * maps runs on the bf16 matrix pipe with each fp32 operand split exactly into three bf16 values and the six
+   * products above 2^-25 |a||b| accumulated in fp32 (csrc/ekf_split.hpp): fp32-class accuracy, not bit-equal
+   * to the fp32 instruction.  fp32 filters only. */
+  EKF_OPT_SPLIT_BF16 = 4
 };
 
 /* Fills `cfg` with the reference defaults (ConfigVSLAM.cpp:27-47, camModel.hpp:22-31). */

@@ -541,3 +541,32 @@ def test_largest_config_n4000_properties():
     f.predict()
     h, vis, rem, S2 = f.predictions()
     assert np.all(np.isfinite(h)) and vis.sum() >= 0.98 * (N - 3)
+
+
+def test_split_bf16_downdate_is_fp32_accurate():
+    """EKF_OPT_SPLIT_BF16 (opt-in): the downdate on the bf16 matrix pipe with 3 x bf16 operands.  Both the exact
+    fp32 path and the split path are measured against the fp64 oracle on the same inputs: the split path has
+    to stay within the fp32 tolerances and within a small factor of the exact path's own error."""
+    n_feat = 530                                             # 25 tile rows: the split kernel is used from 23 up
+    ref, g0 = make_pair(n_feat, np.float32, capacity=n_feat)
+    ref64 = o.build_scenario(o.StructuredFilter, oracle_cfg(), n_feat, np.float64)
+    _, g1 = make_pair(n_feat, np.float32, capacity=n_feat)
+    g1.set_option(4, 1)
+    ref64.predict()
+    vis = ref64.visible_indices()
+    z = o.synthetic_measurements(ref64, vis, seed=1235, sigma=0.5)
+    ref64.update(z, vis)
+    errs = []
+    for g in (g0, g1):
+        g.setFullState(ref.mu)                               # identical fp32 inputs on both
+        g.setSigmaBlock(ref.Sigma)
+        g.predict()
+        g.update(z.astype(np.float32), vis)
+        g.synchronize()
+        mu, S = gpu_state(g)
+        errs.append((relf(mu, ref64.mu), relf(S, ref64.Sigma), np.abs(S - S.T).max() / np.abs(S).max()))
+    (mu0, s0, a0), (mu1, s1, a1) = errs
+    t = TOL[np.float32]
+    assert mu1 < t["mu"] * 5 and s1 < t["S"]
+    assert s1 < 3 * s0 + 1e-6 and mu1 < 3 * mu0 + 1e-6, errs
+    assert a1 <= 1e-6
