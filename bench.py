@@ -229,6 +229,26 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
                                    "unit": "updates/s", "ms_per_step": round(1e3 * (t1 - t0) / args.steps, 4)}
         flt3.close()
 
+        if n_feat >= 600 and not args.split_bf16:
+            # opt-in variant (NOT the headline, not the default): the covariance downdate on the bf16 matrix pipe
+            # with every fp32 operand split exactly into 3 x bf16 (EKF_OPT_SPLIT_BF16; accuracy against fp64 in
+            # tests/test_gpu_parity.py::test_split_bf16_downdate_is_fp32_accurate, tools/split_accuracy.py)
+            flt4 = build_filter(pkg, cfg, n_feat, px0)
+            flt4.set_option(3, args.pipeline)
+            flt4.set_option(4, 1)
+            run_steps(flt4, d_z, d_idx, n_feat, 0, args.warmup, bpf)
+            flt4.synchronize()
+            t0 = time.perf_counter()
+            run_steps(flt4, d_z, d_idx, n_feat, args.warmup, args.steps, bpf)
+            flt4.synchronize()
+            t1 = time.perf_counter()
+            mu4 = flt4.getFullState()
+            result["secondary_split_bf16"] = {
+                "option": "EKF_OPT_SPLIT_BF16 = 1 (off by default)", "value": round(args.steps / (t1 - t0), 2),
+                "unit": "updates/s", "ms_per_step": round(1e3 * (t1 - t0) / args.steps, 4),
+                "run_sane": bool(np.all(np.isfinite(mu4)) and abs(np.linalg.norm(mu4[3:7]) - 1) < 1e-4)}
+            flt4.close()
+
         # second pass, same steps, streaming P-propagate: HBM GB/s of P <- F P F^T + Q
         flt2 = build_filter(pkg, cfg, n_feat, px0)
         flt2.set_option(0, 1)

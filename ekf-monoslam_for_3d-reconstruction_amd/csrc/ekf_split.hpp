@@ -7,7 +7,9 @@
 //     a*b ~= a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1,   accumulated in fp32 by the MFMA,
 // is as accurate as an fp32 multiply-add chain.  v_mfma_f32_32x32x16_bf16 retires 16 k per 32
 // cycles against 2 k per 64 cycles of v_mfma_f32_32x32x2_f32: six of them cost 192 cycles per 16 k
-// where the fp32 instruction needs 512.
+// where the fp32 instruction needs 512.  This first kernel is far from that bound (tools/split_bench.hip:
+// 131 TF fp32-equivalent at K = 2048 against 111-116 for the fp32 kernel; 197 with the staging removed): its
+// fragment reads (12 ds_read_b128 per 24 MFMAs) are not overlapped with the MFMAs yet.
 //
 // Used for the dominant contraction only, the symmetric downdate Sigma -= V_g V_g^T:
 //   k_split_bf16      V (fp32) -> three bf16 planes, once per chunk (the planes are then read ~48 times)
