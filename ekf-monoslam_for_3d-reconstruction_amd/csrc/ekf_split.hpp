@@ -115,10 +115,11 @@ __global__ void __launch_bounds__(256, 2) k_syrk_bf16x3(SplitArgs g) {
           for (int p = 0; p < 2; ++p) lds[(o * 3 + pl) * PLANE + slot[p]] = rg[o][pl][p];
       __syncthreads();
       if (k0 + BK < g.K) load_regs(k0 + BK);
+      // both k16 halves are fetched up front: the reads of the second half land under the MFMAs of the first
+      bf16x8 fa[2][3][2], fb[2][3][2];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {              // two k16 halves
+      for (int s = 0; s < 2; ++s) {
         const int kg = 2 * s + h;
-        bf16x8 fa[3][2], fb[3][2];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
@@ -126,19 +127,21 @@ __global__ void __launch_bounds__(256, 2) k_syrk_bf16x3(SplitArgs g) {
             const int ar = wr * 64 + i * 32 + l31, br = wc * 64 + i * 32 + l31;
             f32x4 va = lds[pl * PLANE + kg * T + (ar ^ (4 * kg))];
             f32x4 vb = lds[(3 + pl) * PLANE + kg * T + (br ^ (4 * kg))];
-            fa[pl][i] = __builtin_bit_cast(bf16x8, va);
-            fb[pl][i] = __builtin_bit_cast(bf16x8, vb);
+            fa[s][pl][i] = __builtin_bit_cast(bf16x8, va);
+            fb[s][pl][i] = __builtin_bit_cast(bf16x8, vb);
           }
-        // smallest products first: a3 b1, a1 b3, a2 b2, a2 b1, a1 b2, a1 b1
-        constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};
+      }
+      // smallest products first: a3 b1, a1 b3, a2 b2, a2 b1, a1 b2, a1 b1
+      constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int q = 0; q < 6; ++q)
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA_[q]][i], fb[PB_[q]][j], acc[i][j], 0, 0, 0);
-      }
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][PA_[q]][i], fb[s][PB_[q]][j], acc[i][j], 0, 0, 0);
     }
     const bool mirror = bi > bj;
 #pragma unroll
