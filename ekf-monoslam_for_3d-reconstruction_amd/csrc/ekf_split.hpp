@@ -10,6 +10,12 @@
 // where the fp32 instruction needs 512.  This first kernel is far from that bound (tools/split_bench.hip:
 // 131 TF fp32-equivalent at K = 2048 against 111-116 for the fp32 kernel; 197 with the staging removed): its
 // fragment reads (12 ds_read_b128 per 24 MFMAs) are not overlapped with the MFMAs yet.
+// Tried and dropped (bit-identical results, no gain): a two-wave 128 x 64 shape (125 TF: the accumulators spill
+// into AGPR copies), an 8-wave ping-pong workgroup with the halves held half a K step apart by the barrier (89 TF:
+// 64 + 96 + 48 registers of accumulators, fragments and staging do not fit the 256 a wave gets at two waves per
+// SIMD; the spills to scratch cost more than the lockstep they remove).  Per-phase accounting says the two
+// workgroups of a CU run in lockstep here (MFMA 3072 + LDS 3000 + L2->L1 1536 cycles per K step add up instead of
+// overlapping): the next form is BK = 16 stages so that the ping-pong fits in registers.
 //
 // Used for the dominant contraction only, the symmetric downdate Sigma -= V_g V_g^T:
 //   k_split_bf16      V (fp32) -> three bf16 planes, once per chunk (the planes are then read ~48 times)
