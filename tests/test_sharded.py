@@ -79,28 +79,31 @@ def test_sharded_orchestration_matches_unsharded_oracle_gloo(world):
     assert seen.all()                      # the panels cover every row of Sigma
 
 
-def _mk_hip(pkg, n_feat):
-    """HIP filter on the scenario of o.build_scenario (velocities set, features added in order)."""
+def _mk_hip(pkg, n_feat, px0=None):
+    """HIP filter on the scenario of o.build_scenario (velocities set, features added in order), or -- with
+    px0 -- on the bench's synthetic stream (camera at rest, its pixels)."""
     cfg = o.Config.kinect()
     flt = pkg.VSlamFilter(pkg.kinect_config(), capacity_features=n_feat, dtype=np.float32)
     flt.setDt(1.0 / 30.0)
-    mu = flt.getFullState()
-    mu[7:10] = (0.3, 0.0, 0.0)
-    mu[10:13] = (0.0, 0.05, 0.0)
-    flt.setFullState(mu)
-    for (u, v) in o.synthetic_pixels(cfg, n_feat):
+    if px0 is None:
+        mu = flt.getFullState()
+        mu[7:10] = (0.3, 0.0, 0.0)
+        mu[10:13] = (0.0, 0.05, 0.0)
+        flt.setFullState(mu)
+        px0 = o.synthetic_pixels(cfg, n_feat)
+    for (u, v) in px0:
         assert flt.addFeature((u, v)) == 1
     return flt
 
 
-def _gpu_worker(rank, world, port, n_feat, frames, z_np, out):
+def _gpu_worker(rank, world, port, n_feat, frames, z_np, out, px0=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from __graft_entry__ import load_package
     pkg = load_package()
     from ekf_monoslam_amd.sharded import HipShardBackend, ShardedStep
-    flt = _mk_hip(pkg, n_feat)
+    flt = _mk_hip(pkg, n_feat, px0)
     b = HipShardBackend(flt, rank, world)
     step = ShardedStep(b)
     d_z = torch.from_numpy(z_np).cuda()
@@ -116,10 +119,10 @@ def _gpu_worker(rank, world, port, n_feat, frames, z_np, out):
     dist.destroy_process_group()
 
 
-def _plain_hip_run(n_feat, frames, z_np):
+def _plain_hip_run(n_feat, frames, z_np, px0=None):
     from __graft_entry__ import load_package
     pkg = load_package()
-    flt = _mk_hip(pkg, n_feat)
+    flt = _mk_hip(pkg, n_feat, px0)
     idx = list(range(n_feat))
     for k in range(frames):
         flt.predict()
@@ -169,6 +172,27 @@ def test_hip_shard_two_ranks_on_one_gpu_match_plain_path():
         mu, rows, S_rows = out[rank]
         assert relf(mu, mu_p) < 1e-5
         assert relf(S_rows, S_p[rows]) < 2e-4
+
+
+@pytest.mark.gpu
+def test_hip_shard_four_ranks_mid_size_match_plain_path():
+    """Row panels that do not sit on tile boundaries (150 features = 900 rows per rank), a chain of 10 block
+    steps in chunks, four ranks sharing the GPU over gloo: every rank's rows must match the plain pipelined path."""
+    n_feat, frames, world = 600, 2, 4
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from ekf_monoslam_amd import synthetic
+    px0, z = synthetic.measurement_stream(pkg.kinect_config(), n_feat, frames, sigma_px=0.5)
+    z_np = np.ascontiguousarray(z.reshape(frames, -1), np.float32)
+    mu_p, S_p = _plain_hip_run(n_feat, frames, z_np, px0)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gpu_worker, args=(world, free_port(), n_feat, frames, z_np, out, px0), nprocs=world, join=True)
+    for rank in range(world):
+        mu, rows, S_rows = out[rank]
+        assert np.all(np.isfinite(mu))
+        assert relf(mu, mu_p) < 2e-5
+        assert relf(S_rows, S_p[rows]) < 5e-4
 
 
 @pytest.mark.gpu
