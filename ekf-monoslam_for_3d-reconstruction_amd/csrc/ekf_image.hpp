@@ -181,9 +181,13 @@ k_ncc_search(const unsigned char* __restrict__ frame, int fw, int fh, const T* _
     if (tid == 0) { found[i] = 0; score[i] = -1.f; z_out[2 * i] = T(-1); z_out[2 * i + 1] = T(-1); }
     return;
   }
-  constexpr int REG = kMaxWindow + 2 * kMaxSearch + 1;
-  __shared__ unsigned char tpl[kMaxWindow * kMaxWindow];
-  __shared__ unsigned char reg[REG * REG];
+  constexpr int REG = kMaxWindow + 2 * kMaxSearch + 1;      // 73: widest / tallest region
+  constexpr int RSMAX = (REG + 3 + 3) & ~3;                 // row stride of the staged region, multiple of 4
+  // template rows padded with zeros to whole 32-bit words; the region as bytes with a word-aligned row stride:
+  // a candidate row is wq + 1 aligned words, realigned with v_alignbyte and multiplied 4 pixels at a time
+  // (v_dot4_u32_u8) -- all sums stay exact integers
+  __shared__ unsigned int tplw[kMaxWindow * (kMaxWindow / 4)];
+  __shared__ __attribute__((aligned(16))) unsigned char reg[REG * RSMAX + 16];
   __shared__ float s_val[256];
   __shared__ int s_idx[256];
   __shared__ int s_st, s_stt;
@@ -222,21 +226,38 @@ k_ncc_search(const unsigned char* __restrict__ frame, int fw, int fh, const T* _
   const int ni = i1 - i0 + 1, nj = j1 - j0 + 1;
   // stage the template and the image region every candidate window can touch
   int st = 0, stt = 0;
-  for (int t = tid; t < w2; t += 256) tpl[t] = M[t];
+  const int wq = (w + 3) >> 2;                               // words per template row
+  for (int t = tid; t < w * wq; t += 256) {
+    const int y = t / wq, k = t % wq;
+    unsigned int v = 0;
+    for (int b = 0; b < 4; ++b)
+      if (4 * k + b < w) v |= (unsigned int)M[y * w + 4 * k + b] << (8 * b);
+    tplw[t] = v;
+  }
   const int rx0 = i0 - hw, ry0 = j0 - hw, rw = ni + w, rh = nj + w;
+  const int RS = (rw + 3 + 3) & ~3;
   const bool region_ok = ni > 0 && nj > 0 && rw <= REG && rh <= REG;
   if (region_ok)
-    for (int t = tid; t < rw * rh; t += 256) {
-      const int yy = ry0 + t / rw, xx = rx0 + t % rw;
-      reg[t] = (yy >= 0 && yy < fh && xx >= 0 && xx < fw) ? frame[(size_t)yy * fw + xx] : 0;
+    for (int t = tid; t < RS * rh + 16; t += 256) {
+      const int ly = t / RS, lx = t % RS;
+      const int yy = ry0 + ly, xx = rx0 + lx;
+      reg[t] = (ly < rh && lx < rw && yy >= 0 && yy < fh && xx >= 0 && xx < fw) ? frame[(size_t)yy * fw + xx] : 0;
     }
+  if (tid == 0) { s_st = 0; s_stt = 0; }
   __syncthreads();
-  if (tid == 0) {
-    for (int t = 0; t < w2; ++t) { st += tpl[t]; stt += tpl[t] * tpl[t]; }
-    s_st = st; s_stt = stt;
+  {
+    int a = 0, b = 0;
+    for (int t = tid; t < w * wq; t += 256) {
+      const unsigned int v = tplw[t];
+      a = __builtin_amdgcn_udot4(v, 0x01010101u, a, false);
+      b = __builtin_amdgcn_udot4(v, v, b, false);
+    }
+    if (a | b) { atomicAdd(&s_st, a); atomicAdd(&s_stt, b); }
   }
   __syncthreads();
   st = s_st; stt = s_stt;
+  const unsigned int lastmask = (w & 3) ? ((1u << (8 * (w & 3))) - 1u) : 0xffffffffu;
+  const unsigned int* regw = reinterpret_cast<const unsigned int*>(reg);
   float best = -1.f;                                         // "float max = -1"
   int best_c = -1;
   if (region_ok) {
@@ -249,12 +270,23 @@ k_ncc_search(const unsigned char* __restrict__ frame, int fw, int fh, const T* _
       const float g = x2c * fi * fi + y2c * fj * fj + yxc * fi * fj;      // the reference's expression, left to right
       if (!(g <= sigma2)) continue;
       int ss = 0, sss = 0, sts = 0;
-      const unsigned char* rp = reg + (cj - hw - ry0) * rw + (ci - hw - rx0);
-      for (int y = 0; y < w; ++y)
-        for (int x = 0; x < w; ++x) {
-          const int a = tpl[y * w + x], b = rp[y * rw + x];
-          ss += b; sss += b * b; sts += a * b;
+      const int o0 = (cj - hw - ry0) * RS + (ci - hw - rx0);     // byte offset of the window's first pixel
+      const int sh = o0 & 3;
+      const unsigned int* rp = regw + (o0 >> 2);
+      for (int y = 0; y < w; ++y) {
+        const unsigned int* rr = rp + y * (RS >> 2);
+        unsigned int lo = rr[0];
+        for (int k = 0; k < wq; ++k) {
+          const unsigned int hi = rr[k + 1];
+          unsigned int bw = __builtin_amdgcn_alignbyte(hi, lo, sh);
+          lo = hi;
+          if (k == wq - 1) bw &= lastmask;
+          const unsigned int aw = tplw[y * wq + k];
+          ss = __builtin_amdgcn_udot4(bw, 0x01010101u, ss, false);
+          sss = __builtin_amdgcn_udot4(bw, bw, sss, false);
+          sts = __builtin_amdgcn_udot4(aw, bw, sts, false);
         }
+      }
       const long long num = nn * sts - (long long)st * ss;
       const long long d2 = nn * sss - (long long)ss * ss;
       const float val = (float)((double)num / sqrt((double)d1 * (double)d2));   // 0/0 -> NaN: never chosen
@@ -283,8 +315,8 @@ k_ncc_search(const unsigned char* __restrict__ frame, int fw, int fh, const T* _
     const int ci = i0 + mc / nj, cj = j0 + mc % nj;
     if (tid == 0) { found[i] = 1; score[i] = mx; z_out[2 * i] = T(ci); z_out[2 * i + 1] = T(cj); }
     // "this->matching_patch = newPatch" (Patch.cpp:286): the matched window replaces the matching template
-    const unsigned char* rp = reg + (cj - hw - ry0) * rw + (ci - hw - rx0);
-    for (int t = tid; t < w2; t += 256) M[t] = rp[(t / w) * rw + (t % w)];
+    const unsigned char* rp = reg + (cj - hw - ry0) * RS + (ci - hw - rx0);
+    for (int t = tid; t < w2; t += 256) M[t] = rp[(t / w) * RS + (t % w)];
   } else if (tid == 0) {
     found[i] = 0;
     score[i] = (mc >= 0) ? mx : -1.f;
