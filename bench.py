@@ -58,8 +58,64 @@ def build_filter(pkg, cfg, n_feat, px0):
     return flt
 
 
-def run_steps(flt, d_z, d_idx, n_feat, first, count, bytes_per_frame):
+def segment_frames(n_feat):
+    """Frames one map may run with EVERY feature measured in EVERY frame before its fp32 covariance stops being
+    positive (the reference's formulation -- single precision, no square root, no feature process noise -- loses
+    positivity there: N = 200 after 5363 frames, 500 after 1241, 1000 after 783 on this stream, the fp64 filter
+    never; tools/long_run.py).  Longer runs continue on a map started afresh from the stream's current pixels: the
+    work per step is the same."""
+    if n_feat <= 200:
+        return 3000
+    return max(100, int(450.0 * (1000.0 / n_feat) ** 1.2))
+
+
+class FilterRing:
+    """`frames` frames of the stream on ceil(frames / seg) maps built before the clock starts; frame f runs on
+    map f // seg, whose features were initialised from the pixels of frame seg * (f // seg) - 1."""
+
+    def __init__(self, pkg, cfg, n_feat, px0, z, frames, options=()):
+        self.seg = segment_frames(n_feat)
+        self.filters = []
+        nseg = max(1, -(-frames // self.seg))
+        if nseg > 64:
+            raise SystemExit(f"--steps {frames}: more than 64 map restarts of {self.seg} frames at N = {n_feat}; use fewer steps")
+        for s in range(nseg):
+            flt = build_filter(pkg, cfg, n_feat, px0 if s == 0 else z[s * self.seg - 1])
+            for k, v in options:
+                flt.set_option(k, v)
+            self.filters.append(flt)
+
+    def at(self, frame):
+        return self.filters[min(frame // self.seg, len(self.filters) - 1)]
+
+    def set_option(self, k, v):
+        for f in self.filters:
+            f.set_option(k, v)
+
+    def profile_reset(self):
+        for f in self.filters:
+            f.profile_reset()
+
+    def profile(self):
+        out = {}
+        for f in self.filters:
+            for k, (ms, cnt) in f.profile().items():
+                a = out.get(k, (0.0, 0))
+                out[k] = (a[0] + ms, a[1] + cnt)
+        return out
+
+    def synchronize(self):
+        for f in self.filters:
+            f.synchronize()
+
+    def close(self):
+        for f in self.filters:
+            f.close()
+
+
+def run_steps(ring, d_z, d_idx, n_feat, first, count, bytes_per_frame):
     for f in range(first, first + count):
+        flt = ring.at(f) if isinstance(ring, FilterRing) else ring
         flt.predict()
         flt.update_device(d_z.data_ptr() + f * bytes_per_frame, d_idx.data_ptr(), n_feat, False)
 
@@ -134,11 +190,10 @@ def main():
 
 
 def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
-    flt = build_filter(pkg, cfg, n_feat, px0)
-    flt.set_option(3, args.pipeline)
-    if args.split_bf16:
-        flt.set_option(4, 1)
-    n = flt.stateDim()
+    frames = args.warmup + args.steps
+    opts = [(3, args.pipeline)] + ([(4, 1)] if args.split_bf16 else [])
+    flt = FilterRing(pkg, cfg, n_feat, px0, z, frames, opts)
+    n = flt.filters[0].stateDim()
     d_z = torch.from_numpy(z.reshape(z.shape[0], -1)).to(dev).contiguous()
     d_idx = torch.arange(n_feat, dtype=torch.int32, device=dev)
     bpf = 2 * n_feat * 4
@@ -160,9 +215,10 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
     ms_per_step = 1e3 * elapsed / args.steps
 
     # sanity of the run: finite state, unit quaternion, every feature still in view
-    mu = flt.getFullState()
-    flt.predict()
-    h, vis, rem, S2 = flt.predictions()
+    last = flt.at(frames - 1)
+    mu = last.getFullState()
+    last.predict()
+    h, vis, rem, S2 = last.predictions()
     sane = bool(np.all(np.isfinite(mu)) and abs(np.linalg.norm(mu[3:7]) - 1) < 1e-4 and int(vis.sum()) >= int(0.98 * n_feat))
 
     m = 2 * n_feat
@@ -200,25 +256,29 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
         "config": {"workload": f"N={n_feat} inverse-depth features, n={n}, M=N measured per frame, "
                                f"fp32, 1xMI355X (BASELINE configs[{2 if n_feat == 1000 else 1}])",
                    "features": n_feat, "state_dim": n, "measured_per_frame": n_feat,
-                   "camera": "conf_kinect.cfg/scale2", "dT": 1.0 / 30.0},
+                   "camera": "conf_kinect.cfg/scale2", "dT": 1.0 / 30.0,
+                   "frames_per_map": flt.seg, "maps": len(flt.filters)},
         "run_sane": sane, "features_visible_at_end": int(vis.sum()), "features_rho_nonpositive_at_end": int(rem.sum()),
         "roofline": roofline,
         "kernel_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()},
     }
+
+    flt.close()                             # the secondary passes build their own maps
 
     if not args.no_propagate_pass:
         # secondary workload: M = 32 measured features per frame, the reference's real
         # operating point (conf_sim.cfg:24-25) -- the dense contractions shrink to rank 64 and the step
         # becomes HBM-bound (W pass + rank-64 downdate stream Sigma)
         m32 = min(32, n_feat)
-        flt3 = build_filter(pkg, cfg, n_feat, px0)
+        flt3 = FilterRing(pkg, cfg, n_feat, px0, z, frames)
         sel = torch.arange(m32, dtype=torch.int32, device=dev)
         d_z32 = d_z[:, :2 * m32].contiguous()
 
         def run32(first, count):
             for f in range(first, first + count):
-                flt3.predict()
-                flt3.update_device(d_z32.data_ptr() + f * 2 * m32 * 4, sel.data_ptr(), m32, False)
+                f3 = flt3.at(f)
+                f3.predict()
+                f3.update_device(d_z32.data_ptr() + f * 2 * m32 * 4, sel.data_ptr(), m32, False)
         run32(0, args.warmup)
         flt3.synchronize()
         t0 = time.perf_counter()
@@ -233,16 +293,14 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
             # opt-in variant (NOT the headline, not the default): the covariance downdate on the bf16 matrix pipe
             # with every fp32 operand split exactly into 3 x bf16 (EKF_OPT_SPLIT_BF16; accuracy against fp64 in
             # tests/test_gpu_parity.py::test_split_bf16_downdate_is_fp32_accurate, tools/split_accuracy.py)
-            flt4 = build_filter(pkg, cfg, n_feat, px0)
-            flt4.set_option(3, args.pipeline)
-            flt4.set_option(4, 1)
+            flt4 = FilterRing(pkg, cfg, n_feat, px0, z, frames, [(3, args.pipeline), (4, 1)])
             run_steps(flt4, d_z, d_idx, n_feat, 0, args.warmup, bpf)
             flt4.synchronize()
             t0 = time.perf_counter()
             run_steps(flt4, d_z, d_idx, n_feat, args.warmup, args.steps, bpf)
             flt4.synchronize()
             t1 = time.perf_counter()
-            mu4 = flt4.getFullState()
+            mu4 = flt4.at(frames - 1).getFullState()
             result["secondary_split_bf16"] = {
                 "option": "EKF_OPT_SPLIT_BF16 = 1 (off by default)", "value": round(args.steps / (t1 - t0), 2),
                 "unit": "updates/s", "ms_per_step": round(1e3 * (t1 - t0) / args.steps, 4),
@@ -250,8 +308,7 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
             flt4.close()
 
         # second pass, same steps, streaming P-propagate: HBM GB/s of P <- F P F^T + Q
-        flt2 = build_filter(pkg, cfg, n_feat, px0)
-        flt2.set_option(0, 1)
+        flt2 = FilterRing(pkg, cfg, n_feat, px0, z, frames, [(0, 1)])
         run_steps(flt2, d_z, d_idx, n_feat, 0, args.warmup, bpf)
         flt2.synchronize()
         flt2.set_option(2, 1)
@@ -278,7 +335,7 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
         flt2.set_option(2, 2)
         flt2.profile_reset()
         for _ in range(20):
-            flt2.predict()
+            flt2.filters[0].predict()
         flt2.synchronize()
         ms, cnt = flt2.profile().get("propagate_strips", (0.0, 0))
         flt2.set_option(2, 0)
@@ -296,7 +353,6 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
                                             "reference's dense n^3 formulation, numpy/OpenBLAS sgemm",
                                   "seconds_per_update": round(t_dense, 3),
                                   "structured_port_updates_per_s": round(1.0 / t_struct, 3)}
-    flt.close()
     return result
 
 

@@ -168,21 +168,33 @@ def bench(pkg, cfg, n_feat, px0, z, args, rank, world, dev):
     import torch.distributed as dist
     if n_feat % world != 0:
         raise SystemExit(f"--features {n_feat} must be divisible by the number of GPUs ({world})")
-    flt = pkg.VSlamFilter(cfg, capacity_features=n_feat, dtype=np.float32, device=dev.index)
-    flt.setDt(1.0 / 30.0)
-    for (u, v) in px0:
-        if flt.addFeature((u, v)) != 1:
-            raise RuntimeError("synthetic pixel rejected by addFeature")
-    flt.synchronize()
-    backend = HipShardBackend(flt, rank, world, stream=torch.cuda.current_stream().cuda_stream)
-    stepper = ShardedStep(backend)
+    # a map runs `seg` frames (bench.segment_frames: the fp32 covariance of a map whose features are ALL measured in
+    # EVERY frame stops being positive after a few hundred frames); longer runs continue on a map started afresh
+    # from the stream's current pixels -- all maps are built before the clock starts
+    import bench as _bench
+    seg = _bench.segment_frames(n_feat)
+    frames = args.warmup + args.steps
+    nseg = max(1, -(-frames // seg))
+    if nseg > 64:
+        raise SystemExit(f"--steps {frames}: more than 64 map restarts of {seg} frames at N = {n_feat}; use fewer steps")
+    maps = []
+    for sgi in range(nseg):
+        f_ = pkg.VSlamFilter(cfg, capacity_features=n_feat, dtype=np.float32, device=dev.index)
+        f_.setDt(1.0 / 30.0)
+        for (u, v) in (px0 if sgi == 0 else z[sgi * seg - 1]):
+            if f_.addFeature((u, v)) != 1:
+                raise RuntimeError("synthetic pixel rejected by addFeature")
+        f_.synchronize()
+        b_ = HipShardBackend(f_, rank, world, stream=torch.cuda.current_stream().cuda_stream)
+        maps.append((f_, ShardedStep(b_)))
+    flt, stepper = maps[0]
     d_z = torch.from_numpy(z.reshape(z.shape[0], -1)).to(dev).contiguous()
     bpf = 2 * n_feat * 4
     n = flt.stateDim()
 
     def run(first, count):
         for f in range(first, first + count):
-            stepper.step(d_z.data_ptr() + f * bpf)
+            maps[min(f // seg, nseg - 1)][1].step(d_z.data_ptr() + f * bpf)
 
     run(0, args.warmup)
     torch.cuda.synchronize()
@@ -198,7 +210,7 @@ def bench(pkg, cfg, n_feat, px0, z, args, rank, world, dev):
     dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
 
-    mu = flt.getFullState()
+    mu = maps[min((frames - 1) // seg, nseg - 1)][0].getFullState()
     sane = bool(np.all(np.isfinite(mu)) and abs(np.linalg.norm(mu[3:7]) - 1) < 1e-4)
     # per-phase share of one step on this rank (HIP events around every kernel, separate short pass)
     flt.set_option(2, 2)
@@ -235,12 +247,14 @@ def bench(pkg, cfg, n_feat, px0, z, args, rank, world, dev):
         "config": {"workload": f"N={n_feat} inverse-depth features, n={n}, M=N measured per frame, fp32, "
                                f"row-panel shard over {world} GPUs (BASELINE configs[3])",
                    "features": n_feat, "state_dim": n, "measured_per_frame": n_feat,
-                   "parallelism": f"row-panel shard x{world}: all-gather H, S, V over RCCL"},
+                   "parallelism": f"row-panel shard x{world}: all-gather H, S, V over RCCL",
+                   "frames_per_map": seg, "maps": nseg},
         "run_sane": sane,
         "per_rank_kernel_ms": phase,
         "jacobian_innovation_shard_ms": round(shard_ms, 4),
         "allgather_ms_per_step": gather_ms,
         "roofline": roofline, "cpu_baseline": None,
     }
-    flt.close()
+    for f_, _ in maps:
+        f_.close()
     return result
