@@ -794,6 +794,12 @@ struct Filter : FilterBase {
         return;
       }
     }
+    if constexpr (!kIsF32) {
+      if (opt_mfma) {                            // fp64 matrix pipe, same 64 x 64 tile contract as the VALU kernel
+        k_gemm_mfma_f64<ROLE, BT><<<grid, 256, 0, st>>>(g);
+        return;
+      }
+    }
     k_gemm_valu<T, ROLE, BT><<<grid, 256, 0, st>>>(g);
   }
 

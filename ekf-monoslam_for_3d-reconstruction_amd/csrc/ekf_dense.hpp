@@ -497,6 +497,151 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmArgs g) {   // two wor
   }  // tile loop
 }
 
+// ---------------------------------------------------------------------------------------
+// fp64 MFMA tile GEMM (v_mfma_f64_16x16x4_f64), same contract as k_gemm_valu<double> with its 64 x 64 tile:
+// 256 lanes = 4 waves (2 x 2), each wave 32 x 32 = 2 x 2 accumulators of 16 x 16 (4 doubles per lane:
+// register e holds row 4 e + lane / 16, column lane % 16; tools/f64_mfma_probe.hip).  BK = 16.  LDS image per operand: [q = k / 2][row] slots of two
+// doubles (16 bytes), slot = q * 64 + (row ^ q): one ds_read_b128 feeds two MFMAs -- lane group kq = lane / 16
+// of read u holds k = 8 u + 2 kq + {0, 1}, the same k permutation on A and B, so every product is there once.
+// NN mode stages B by 2 x 2 register transposes of row-major [k][col] pairs.  Two LDS stages, one barrier per
+// K step, as in the fp32 kernel.
+// ---------------------------------------------------------------------------------------
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+template <int ROLE, bool BT>
+__global__ void __launch_bounds__(256) k_gemm_mfma_f64(GemmArgs g) {
+  constexpr int TS = 64, BK = 16, NQ = BK / 2;
+  const double* A = static_cast<const double*>(g.A);
+  const double* B = static_cast<const double*>(g.B);
+  double* C = static_cast<double*>(g.C);
+  const int lda = g.lda, ldb = g.ldb, ldc = g.ldc;
+  const double alpha = g.alpha, beta = g.beta;
+  __shared__ f64x2 lds[2 * NQ * 2 * TS];         // two stages of {A image, B image}: 32 KiB
+  __shared__ int s_tile;
+  constexpr int STAGE = NQ * 2 * TS;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int kq = lane >> 4, l15 = lane & 15;
+  if (ROLE == ROLE_PANEL || ROLE == ROLE_TRAILING) __builtin_amdgcn_s_setprio(2);
+  int bi, bj, iter = 0;
+  while (gemm_next_tile(g, &s_tile, iter, bi, bj)) {
+  const int grow0 = g.row_off + bi * TS, gcol0 = g.col_off + bj * TS;
+  if (g.tri && grow0 + TS <= gcol0) continue;
+  if (g.zrow && grow0 >= g.zrow && gcol0 >= g.zcol_end) continue;
+  const int K = g.ktri ? min(g.K, (bj + g.ktile_off + 1) * TS) : g.K;
+  // staging: 64 rows x 8 slots per operand = 512 slots, 2 per lane (NT); NN: one (k pair, column pair) per lane
+  const double* Ag[2];
+  const double* Bg[2];
+  int aslot[2], bslot[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int idx = tid + 256 * p;
+    const int row = idx >> 3, q = idx & 7;
+    Ag[p] = A + (size_t)(bi * TS + row) * lda + 2 * q;
+    aslot[p] = q * TS + (row ^ q);
+    if (!BT) {
+      Bg[p] = B + (size_t)(bj * TS + row) * ldb + 2 * q;
+      bslot[p] = aslot[p];
+    }
+  }
+  if (BT) {
+    const int q = tid >> 5, cp = tid & 31;       // k pair q (8), column pair cp (32)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      Bg[p] = B + (size_t)(2 * q + p) * ldb + bj * TS + 2 * cp;     // row k = 2q + p, columns 2cp, 2cp + 1
+      bslot[p] = q * TS + ((2 * cp + p) ^ q);                        // slot of column 2cp + p
+    }
+  }
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (beta != 0.0) {
+        const double cs = beta / alpha;
+        const double* Cp = C + (size_t)(bi * TS + wr * 32 + i * 16 + kq) * ldc + bj * TS + wc * 32 + j * 16 + l15;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = cs * Cp[(size_t)(4 * e) * ldc];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0;
+      }
+    }
+  f64x2 ra[2], rb[2];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      ra[p] = *reinterpret_cast<const f64x2*>(Ag[p] + k0);
+      rb[p] = BT ? *reinterpret_cast<const f64x2*>(Bg[p] + (size_t)k0 * ldb) : *reinterpret_cast<const f64x2*>(Bg[p] + k0);
+    }
+  };
+  auto store_tile = [&](int stage) {
+    f64x2* As = lds + stage * STAGE;
+    f64x2* Bs = As + NQ * TS;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) As[aslot[p]] = ra[p];
+    if (!BT) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) Bs[bslot[p]] = rb[p];
+    } else {
+      // rb[0] = B[2q][c, c+1], rb[1] = B[2q+1][c, c+1]  ->  column c: (B[2q][c], B[2q+1][c]), column c+1 likewise
+      f64x2 t0 = {rb[0][0], rb[1][0]}, t1 = {rb[0][1], rb[1][1]};
+      Bs[bslot[0]] = t0;
+      Bs[bslot[1]] = t1;
+    }
+  };
+  __syncthreads();
+  load_tile(0);
+  store_tile(0);
+  if (BK < K) load_tile(BK);
+  __syncthreads();
+  int stage = 0;
+  for (int k0 = 0; k0 < K; k0 += BK, stage ^= 1) {
+    if (k0 + BK < K) {
+      store_tile(stage ^ 1);
+      if (k0 + 2 * BK < K) load_tile(k0 + 2 * BK);
+    }
+    const f64x2* As = lds + stage * STAGE;
+    const f64x2* Bs = As + NQ * TS;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q = 4 * u + kq;
+      f64x2 fa[2], fb[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int ar = wr * 32 + t * 16 + l15, br = wc * 32 + t * 16 + l15;
+        fa[t] = As[q * TS + (ar ^ q)];
+        fb[t] = Bs[q * TS + (br ^ q)];
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const bool mirror = (g.tri == 2) && (grow0 >= gcol0 + TS);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = bj * TS + wc * 32 + j * 16 + l15;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = bi * TS + wr * 32 + i * 16 + 4 * e + kq;
+        const double x = alpha * acc[i][j][e];
+        C[(size_t)r * ldc + c] = x;
+        if (mirror) C[(size_t)(c + g.col_off - g.row_off) * ldc + (r + g.row_off - g.col_off)] = x;
+      }
+    }
+  }  // tile loop
+}
+
 // Identity strip of the chunked factorisation (rows = widest chunk): see ChunkTab / strip_is_one.
 template <typename T>
 __global__ void k_set_identity_strip(T* __restrict__ Z, int ldz, int m_pad, ChunkTab tab) {

@@ -66,7 +66,8 @@ enum ekf_option {
    * Sigma' = F Sigma F^T + Q (reads n^2, writes n^2 -- the formulation the reference's
    * `.eval()` at vR.cpp:477 has, and the one the HBM roofline of P-propagate is quoted on). */
   EKF_OPT_PROPAGATE_STREAMING = 0,
-  /* 1 (default): hand-written MFMA kernels for the dense contractions; 0: plain VALU tiles. */
+  /* 1 (default): hand-written MFMA kernels for the dense contractions (fp32: v_mfma_f32_32x32x2_f32,
+   * fp64: v_mfma_f64_16x16x4_f64); 0: plain VALU tiles. */
   EKF_OPT_USE_MFMA = 1,
   /* profiling level: 0 off, 1 HIP events around the dominant kernels (downdate, streaming propagate),
    * 2 around every kernel (each pair of events costs a few microseconds of launch gap). */

@@ -63,7 +63,7 @@ def test_predict_matches_oracle(dtype, streaming):
     assert relf(S, ref.Sigma) < t["S"]
 
 
-@pytest.mark.parametrize("dtype,mfma", [(np.float64, False), (np.float32, False), (np.float32, True)])
+@pytest.mark.parametrize("dtype,mfma", [(np.float64, False), (np.float64, True), (np.float32, False), (np.float32, True)])
 @pytest.mark.parametrize("n_feat", [20, 50])
 def test_update_matches_oracle(dtype, mfma, n_feat):
     ref, g = make_pair(n_feat, dtype, mfma=mfma)
@@ -408,7 +408,7 @@ def test_two_stage_update_with_rescue(dtype):          # vR.cpp:964-1130, 1245-1
     assert relf(mu, ref.mu) < t["mu"] * 10 and relf(S, ref.Sigma) < t["S"] * 2
 
 
-@pytest.mark.parametrize("dtype,mfma,chunks", [(np.float64, False, 3), (np.float32, True, 3), (np.float32, True, 2),
+@pytest.mark.parametrize("dtype,mfma,chunks", [(np.float64, False, 3), (np.float64, True, 3), (np.float32, True, 3), (np.float32, True, 2),
                                               (np.float32, False, 4)])
 def test_chunked_pipeline_matches_oracle(dtype, mfma, chunks):
     """The chunked factorisation on two streams (what N = 1000 runs by default), forced on a map small
