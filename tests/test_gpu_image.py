@@ -149,3 +149,52 @@ def test_image_error_paths():
     g.predict()
     z, found, score = g.findMatches()                           # empty map
     assert z.shape == (0, 2) and found.size == 0
+
+
+@pytest.mark.parametrize("window,cfg_name", [(30, "sim"), (21, "kinect"), (32, "kinect"), (9, "kinect")])
+def test_other_window_sizes(window, cfg_name):
+    """Template edges that are even, not a multiple of 4, the largest supported and a small one (conf_sim.cfg has
+    window_size = 30, sigma_size = 4; ConfigVSLAM's default is 21): capture, blur and search against the oracle."""
+    pkg = load_package()
+    base_o = o.Config.sim() if cfg_name == "sim" else o.Config.kinect()
+    cfg = dataclasses.replace(base_o, window_size=window, kernel_size=2, T_camera=0.5)
+    gcfg = dict(pkg.sim_config() if cfg_name == "sim" else pkg.kinect_config())
+    gcfg.update(window_size=window, kernel_size=2, T_camera=0.5)
+    n_feat = 16
+    frame = io_.random_texture(cfg.image_height, cfg.image_width, seed=40 + window)
+    ref = o.build_scenario(o.StructuredFilter, cfg, n_feat, np.float32, w=(0.3, 0.9, -0.2))
+    g = pkg.VSlamFilter(gcfg, capacity_features=n_feat, dtype=np.float32)
+    g.setDt(ref.dT)
+    full = g.getFullState()
+    full[7:13] = ref.mu[7:13]
+    g.setFullState(full)
+    g.setFrame(frame)
+    px = o.synthetic_pixels(cfg, n_feat)
+    for (u, v) in px:
+        assert g.addFeature((u, v)) == 1
+    g.setFullState(ref.mu)
+    g.setSigmaBlock(ref.Sigma)
+    tpl = [io_.capture_patch(frame, u, v, window) for (u, v) in px]
+    for i in range(n_feat):
+        assert np.array_equal(g.getPatch(i), tpl[i])
+    ref.predict()
+    g.predict()
+    h, vis, rem, S2 = g.predictions()
+    hb = g.blurPredictions()
+    for i, ft in enumerate(ref.features):
+        if ft.is_in_innovation:
+            assert np.array_equal(g.getPatch(i, matching=True), io_.matching_patch(tpl[i], h[i], hb[i], cfg.kernel_size)), i
+    moved = np.roll(np.roll(frame, -1, axis=1), 2, axis=0)
+    g.setFrame(moved)
+    z, found, score = g.findMatches()
+    checked = 0
+    for i, ft in enumerate(ref.features):
+        if not ft.is_in_innovation:
+            continue
+        mp_ = io_.matching_patch(tpl[i], h[i], hb[i], cfg.kernel_size)
+        ok, zz, sc, win = io_.find_match(moved, mp_, h[i], S2[i], cfg.sigma_size)
+        assert bool(found[i]) == ok and tuple(int(v) for v in z[i]) == tuple(zz), i
+        if np.isfinite(sc):
+            assert abs(float(score[i]) - float(sc)) < 1e-6
+        checked += 1
+    assert checked >= 8

@@ -26,3 +26,17 @@ for mfma in (1, 0):
     f.synchronize(); t1 = time.perf_counter()
     print(f"fp64 N={N} mfma={mfma}: {1e3 * (t1 - t0) / steps:.3f} ms/step  ({steps / (t1 - t0):.1f} updates/s, host-buffer update)")
     f.close()
+
+f = pkg.VSlamFilter(cfg, capacity_features=N, dtype=np.float64)
+f.setDt(1 / 30.0)
+for (u, v) in px0:
+    assert f.addFeature((u, v)) == 1
+zz = z.astype(np.float64)
+for k in range(3):
+    f.predict(); f.update(zz[k].reshape(-1), idx)
+f.synchronize(); f.set_option(2, 2); f.profile_reset()
+for k in range(3, 13):
+    f.predict(); f.update(zz[k].reshape(-1), idx)
+f.synchronize()
+for name, (ms, cnt) in sorted(f.profile().items(), key=lambda kv: -kv[1][0]):
+    print(f"  {name:20s} {ms / 10:8.4f} ms/step  {cnt // 10:4d} launches/step  avg {1e3 * ms / max(cnt, 1):8.1f} us")
