@@ -755,6 +755,29 @@ k_chol_diag(T* __restrict__ Aglob, int ld, T* __restrict__ Dinv, int* __restrict
 #pragma unroll
         for (int e = 0; e < 4; ++e) a[(prow0 + 4 * lq + e) * LDA + c0 + lr] = acc[e];
       }
+    } else if constexpr (sizeof(T) == 8) {
+      // fp64: the same tiles on v_mfma_f64_16x16x4_f64 (register e = row 4 e + lane / 16, column lane % 16)
+      typedef double d4 __attribute__((ext_vector_type(4)));
+      const int ncb = ntop / 16;
+      const int ntiles = (NB / 16) * ncb;
+      const int lr = lane & 15, lq = lane >> 4;
+      for (int t = wave; t < ntiles; t += NT / 64) {
+        const int rb = t / ncb, cb = t % ncb;
+        const int lrow0 = rb * 16;
+        const int prow0 = (lrow0 < ntop) ? (K0 + 16 + lrow0) : (NB + (lrow0 - ntop));
+        const int c0 = K0 + 16 + cb * 16;
+        d4 acc;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = a[(prow0 + 4 * e + lq) * LDA + c0 + lr];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const double av = -a[(prow0 + lr) * LDA + K0 + 4 * s4 + lq];
+          const double bv = a[(c0 + lr) * LDA + K0 + 4 * s4 + lq];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[(prow0 + 4 * e + lq) * LDA + c0 + lr] = acc[e];
+      }
     } else {
       constexpr int RT = NB / 32;                  // logical rows per lane
       const int ncg = ntop / 4;                    // column groups of 4
