@@ -1530,6 +1530,7 @@ struct Filter : FilterBase {
     struct Rows { int r0, count; };
     const Rows ranges[3] = {{0, sh_p0 > 0 ? nb : 0}, {sh_p0, sh_prows}, {npad_live, nb}};
     int step = 0;
+    bool b_inflight = false;
     for (int gi = 0; gi < tab.n; ++gi) {
       const int c0 = step * nb, c1 = cend[gi] * nb, width = c1 - c0;
       for (; step < cend[gi]; ++step) {
@@ -1556,18 +1557,36 @@ struct Filter : FilterBase {
                                              nullptr, nullptr, 0, m_pad, c1);
         }
       }
+      // the rank's solve / W update of every chunk but the last runs beside the (replicated) chain on the CU-masked
+      // second stream, as in Filter::update -- unless the caller's stream is the legacy default stream, which
+      // synchronises implicitly with every other stream (the two would only take turns)
+      const bool overlap = (stream_b != nullptr) && (stream != nullptr) && (gi + 1 < tab.n);
+      hipStream_t ss = overlap ? stream_b : stream;
+      if (overlap) {
+        HIPCHK(hipEventRecord(ev_chain[gi], stream));
+        HIPCHK(hipStreamWaitEvent(stream_b, ev_chain[gi], 0));
+        b_inflight = true;
+      } else if (b_inflight) {
+        HIPCHK(hipEventRecord(ev_b, stream_b));
+        HIPCHK(hipStreamWaitEvent(stream, ev_b, 0));
+        b_inflight = false;
+      }
       for (const Rows& rr : ranges) {
         if (rr.count == 0) continue;
         const size_t off = (size_t)rr.r0 * ldy;
-        { Scope sc(this, KID_SOLVE);
+        { Scope sc(this, KID_SOLVE, ss);
           gemm<ROLE_SOLVE, true>(d_W + off + c0, ldy, Zs + c0, ldy, d_V + off + c0, ldy, rr.count, width, width, T(1), T(0),
-                                 0, 0, 0, 1); }
+                                 0, 0, 0, 1, 0, ss); }
         if (c1 < m_pad) {
-          Scope sc(this, KID_WUPDATE);
+          Scope sc(this, KID_WUPDATE, ss);
           gemm<ROLE_WUPDATE, false>(d_V + off + c0, ldy, Y + (size_t)c1 * ldy + c0, ldy, d_W + off + c1, ldy, rr.count,
-                                    m_pad - c1, width, T(-1), T(1), 0, 0, 0, 0);
+                                    m_pad - c1, width, T(-1), T(1), 0, 0, 0, 0, 0, ss);
         }
       }
+    }
+    if (b_inflight) {
+      HIPCHK(hipEventRecord(ev_b, stream_b));
+      HIPCHK(hipStreamWaitEvent(stream, ev_b, 0));
     }
     HIPCHK(hipGetLastError());
     last_nchunks = tab.n;

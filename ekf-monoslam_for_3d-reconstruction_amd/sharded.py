@@ -177,6 +177,10 @@ def bench(pkg, cfg, n_feat, px0, z, args, rank, world, dev):
     nseg = max(1, -(-frames // seg))
     if nseg > 64:
         raise SystemExit(f"--steps {frames}: more than 64 map restarts of {seg} frames at N = {n_feat}; use fewer steps")
+    # everything of the step -- library phases and collectives -- is ordered on ONE non-default stream: on the legacy
+    # default stream every kernel would synchronise with the library's internal second stream
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(side)
     maps = []
     for sgi in range(nseg):
         f_ = pkg.VSlamFilter(cfg, capacity_features=n_feat, dtype=np.float32, device=dev.index)
