@@ -1012,7 +1012,14 @@ struct Filter : FilterBase {
             if constexpr (kIsF32)
               k_chol_diag_packed<><<<1, 512, 0, sc_>>>(Ajj, ldy, Dj, d_status, std::max(1, std::min(8, (m - j + 15) / 16)));
           } else {
-            k_chol_diag<T, 64><<<1, 512, diag_lds(64), sc_>>>(Ajj, ldy, Dj, d_status);
+            if constexpr (!kIsF32) {
+              if (opt_mfma)
+                k_chol_diag_packed_f64<<<1, 512, 0, sc_>>>(Ajj, ldy, Dj, d_status, std::max(1, std::min(4, (m - j + 15) / 16)));
+              else
+                k_chol_diag<T, 64><<<1, 512, diag_lds(64), sc_>>>(Ajj, ldy, Dj, d_status);
+            } else {
+              k_chol_diag<T, 64><<<1, 512, diag_lds(64), sc_>>>(Ajj, ldy, Dj, d_status);
+            }
           }
         }
         // rows that change at this step: S rows below the diagonal block, then strip rows [0, r0 - c0)
@@ -1542,7 +1549,14 @@ struct Filter : FilterBase {
             if constexpr (kIsF32)
               k_chol_diag_packed<><<<1, 512, 0, stream>>>(Ajj, ldy, Dj, d_status, std::max(1, std::min(8, (sh_m - j + 15) / 16)));
           } else {
-            k_chol_diag<T, 64><<<1, 512, diag_lds(64), stream>>>(Ajj, ldy, Dj, d_status);
+            if constexpr (!kIsF32) {
+              if (opt_mfma)
+                k_chol_diag_packed_f64<<<1, 512, 0, stream>>>(Ajj, ldy, Dj, d_status, std::max(1, std::min(4, (sh_m - j + 15) / 16)));
+              else
+                k_chol_diag<T, 64><<<1, 512, diag_lds(64), stream>>>(Ajj, ldy, Dj, d_status);
+            } else {
+              k_chol_diag<T, 64><<<1, 512, diag_lds(64), stream>>>(Ajj, ldy, Dj, d_status);
+            }
           } }
         const int r0 = j + nb;
         const int vrows = m_pad - c0;

@@ -1023,4 +1023,137 @@ __global__ void k_copy2d(const T* __restrict__ src, int lds_, T* __restrict__ ds
     if (r < rows) dst[(size_t)r * ldd + c] = src[(size_t)r * lds_ + c];
 }
 
+// ---------------------------------------------------------------------------------------
+// fp64 diagonal block, packed, NB = 64: the structure of k_chol_diag_packed (one LDS image with L in the lower and
+// Z = L^-T in the strict upper triangle, 16 x 16 factor + inverse in the registers of wave 0, panel and rank-16
+// updates on the matrix pipe, look-ahead factor) on v_mfma_f64_16x16x4_f64.  Register e of an accumulator holds
+// row 4 e + lane / 16, column lane % 16.
+// ---------------------------------------------------------------------------------------
+typedef double f64x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void diag_tile_update_f64(double* a, int LDA, int prow0, int c0, int K0, bool masked,
+                                                     const double* rinv, int lr, int lq) {
+  f64x4_t acc;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] = a[(prow0 + 4 * e + lq) * LDA + c0 + lr];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    const int k = 4 * s4 + lq;
+    double av = a[(prow0 + lr) * LDA + K0 + k];
+    if (masked) av = (k > lr) ? av : ((k == lr) ? rinv[lr] : 0.0);
+    const double bv = a[(c0 + lr) * LDA + K0 + k];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av, bv, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) a[(prow0 + 4 * e + lq) * LDA + c0 + lr] = acc[e];
+}
+
+__device__ __forceinline__ void diag_factor16_f64(double* a, int LDA, int K0, double* x16, double* rinv, int lane,
+                                                  int* status) {
+  const int i = lane & 15;
+  double r[16], inv[16], x[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) r[j] = (j <= i) ? a[(K0 + i) * LDA + K0 + j] : 0.0;
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const double pk = lane_bcast(r[k], k);
+    if (!(pk > 0.0)) bad = true;
+    inv[k] = 1.0 / sqrt(pk > 0.0 ? pk : 1.0);
+    double acc = 0.0;
+#pragma unroll
+    for (int t = 0; t < k; ++t) acc += lane_bcast(r[t], k) * x[t];
+    const double lik = (i == k) ? sqrt(pk > 0.0 ? pk : 1.0) : r[k] * inv[k];
+    r[k] = lik;
+#pragma unroll
+    for (int j = k + 1; j < 16; ++j) r[j] -= lik * lane_bcast(lik, j);
+    x[k] = (k == i) ? inv[k] : -inv[k] * acc;
+    if (k < i) x[k] = 0.0;
+  }
+  if (bad && lane == 0) status[0] = 1;
+  if (lane < 16) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j <= i) a[(K0 + i) * LDA + K0 + j] = r[j];        // L16
+      else a[(K0 + i) * LDA + K0 + j] = x[j];               // Z16[i][j] = X[j][i]
+      x16[j * 17 + i] = x[j];                               // X16[j][i]
+    }
+    rinv[i] = inv[i];
+  }
+}
+
+__global__ void __launch_bounds__(512)
+k_chol_diag_packed_f64(double* __restrict__ Aglob, int ld, double* __restrict__ Dinv, int* __restrict__ status,
+                       int nblk_real = 4) {
+  constexpr int NB = 64, LDA = NB + 1, NT = 512, NBLK = NB / 16;
+  __shared__ double a[NB * LDA];
+  __shared__ double x16[2][16 * 17];
+  __shared__ double rinv[2][16];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  __builtin_amdgcn_s_setprio(3);
+  for (int idx = tid; idx < NB * NB; idx += NT) {
+    const int i = idx / NB, j = idx % NB;
+    a[i * LDA + j] = (j <= i) ? Aglob[(size_t)i * ld + j] : 0.0;
+  }
+  __syncthreads();
+  if (wave == 0) diag_factor16_f64(a, LDA, 0, x16[0], rinv[0], lane, status);
+  __syncthreads();
+  for (int b = 0; b < NBLK; ++b) {
+    const int K0 = b * 16;
+    const double* xb = x16[b & 1];
+    const double* rb_inv = rinv[b & 1];
+    const int nbelow = NBLK - 1 - b;
+    // panel: row blocks {below} + {Z rows of earlier blocks}: NBLK - 1 of them, P = Y X16^T
+    if (wave < NBLK - 1) {
+      const int prow0 = (wave < nbelow) ? (K0 + 16 + wave * 16) : ((wave - nbelow) * 16);
+      f64x4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const double av = a[(prow0 + lr) * LDA + K0 + 4 * s4 + lq];
+        const double bv = xb[lr * 17 + 4 * s4 + lq];                 // B[k][col] = X16[col][k]
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[(prow0 + 4 * e + lq) * LDA + K0 + lr] = acc[e];
+    }
+    __syncthreads();
+    if (nbelow == 0 || b + 1 >= nblk_real) break;
+    // urgent tiles: block column b + 1 (the nbelow tiles at / below the diagonal + the Z tiles of row blocks 0..b)
+    if (wave < NBLK) {
+      const bool top = wave < nbelow;
+      const int prow0 = top ? (K0 + 16 + wave * 16) : ((wave - nbelow) * 16);
+      diag_tile_update_f64(a, LDA, prow0, K0 + 16, K0, !top && (wave - nbelow) == b, rb_inv, lr, lq);
+    }
+    __syncthreads();
+    // wave 0 factors block b + 1 while the other waves apply the rest of update b (block columns b + 2 ..)
+    if (wave == 0) {
+      diag_factor16_f64(a, LDA, K0 + 16, x16[(b + 1) & 1], rinv[(b + 1) & 1], lane, status);
+    } else {
+      const int nb1 = nbelow - 1;
+      const int ntri = nb1 * (nb1 + 1) / 2;
+      const int nz = (b + 1) * nb1;
+      for (int t = wave - 1; t < ntri + nz; t += NT / 64 - 1) {
+        if (t < ntri) {
+          int rb = 0, rem = t;
+          while (rem > rb) { rem -= rb + 1; ++rb; }
+          diag_tile_update_f64(a, LDA, K0 + 32 + rb * 16, K0 + 32 + rem * 16, K0, false, rb_inv, lr, lq);
+        } else {
+          const int u = t - ntri;
+          const int tb = u / nb1, cb = u % nb1;
+          diag_tile_update_f64(a, LDA, tb * 16, K0 + 32 + cb * 16, K0, tb == b, rb_inv, lr, lq);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int idx = tid; idx < NB * NB; idx += NT) {
+    const int i = idx / NB, j = idx % NB;
+    const double l = a[i * LDA + j];
+    Aglob[(size_t)i * ld + j] = (j <= i) ? l : 0.0;
+    Dinv[(size_t)i * NB + j] = (j < i) ? a[j * LDA + i] : ((j == i) ? 1.0 / l : 0.0);
+  }
+}
+
 }  // namespace ekf
