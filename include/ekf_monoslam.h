@@ -138,7 +138,11 @@ int ekf_get_predictions(ekf_filter* f, void* h, unsigned char* visible,
  * St = H Sigma H^T + R, Kt = Sigma H^T St^-1, mu += Kt (z - h), Sigma <- (I - Kt H) Sigma,
  * normalizeQuaternion (vR.cpp:1625-1642).  `indices` (ascending feature indices, M of them)
  * is the measured set, z holds 2 pixels per listed feature.  plane_constraint != 0 appends
- * the forsePlane pseudo-measurement (vR.cpp:1250-1263, 1272).  M = 0 and no plane: no-op. */
+ * the forsePlane pseudo-measurement (vR.cpp:1250-1263, 1272).  M = 0 and no plane: no-op.
+ * A factorisation of St that meets a non-positive pivot is reported as EKF_ERR_NUMERIC by the next
+ * synchronising call (ekf_synchronize, any getter).  With fp32 this is where a map ends up whose features are
+ * ALL measured in EVERY frame for hundreds of frames (the formulation keeps no square root and the features
+ * carry no process noise: N = 1000 after ~780 frames, N = 200 after ~5400); an EKF_F64 filter does not. */
 int ekf_update(ekf_filter* f, const void* z, const int* indices, int M, int plane_constraint);
 /* Same with z / indices already resident in device memory. */
 int ekf_update_device(ekf_filter* f, const void* d_z, const int* d_indices, int M,
