@@ -260,7 +260,7 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
         "vs_baseline": None, "dtype": "f32 (downdate: 3 x bf16 split operands, f32 accumulate)" if args.split_bf16 else "f32",
         "data": "synthetic",
         "config": {"workload": f"N={n_feat} inverse-depth features, n={n}, M=N measured per frame, "
-                               f"fp32, 1xMI355X (BASELINE configs[{2 if n_feat == 1000 else 1}])",
+                               f"fp32, 1xMI355X ({ {200: 'BASELINE configs[1]', 1000: 'BASELINE configs[2]', 4000: 'BASELINE configs[4] size on one GPU'}.get(n_feat, 'custom size') })",
                    "features": n_feat, "state_dim": n, "measured_per_frame": n_feat,
                    "camera": "conf_kinect.cfg/scale2", "dT": 1.0 / 30.0,
                    "frames_per_map": flt.seg, "maps": len(flt.filters)},
