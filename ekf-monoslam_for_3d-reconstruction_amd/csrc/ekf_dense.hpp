@@ -304,6 +304,19 @@ __global__ void __launch_bounds__(256) k_gemm_valu(GemmArgs g) {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef EKF_GEMM_STAMP
+// Diagnostic build only (tools/clock_probe.hip): shader-clock and 100 MHz stamps around the tile loop of every
+// workgroup and per-phase cycle sums of wave 0, written to buffers nothing else reads.  The library is never built
+// with this macro.
+__device__ unsigned long long ekf_stamp_buf[4 * 1024];
+__device__ unsigned long long ekf_phase_buf[8 * 1024];   // fetch, prologue, K loop, epilogue cycles; tiles
+#define EKF_PHASE_STAMP(var) \
+  do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); \
+       __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define EKF_PHASE_STAMP(var) do { } while (0)
+#endif
+
 template <int ROLE, bool BT, int TM = 128, int TN = 128>
 __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmArgs g) {   // two workgroups per CU: <= 256 registers per lane
   // TM x TN output tile (64 or 128 each), 4 waves as 2 x 2, each wave (TM/2) x (TN/2) = MI x NJ
@@ -326,7 +339,17 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmArgs g) {   // two wor
   if (g.stagger && g.tile_map && blockIdx.x >= gridDim.x / 2)
     for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   int bi, bj, iter = 0;
+#ifdef EKF_GEMM_STAMP
+  if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 1024) {
+    ekf_stamp_buf[4 * blockIdx.x] = __builtin_amdgcn_s_memtime();
+    ekf_stamp_buf[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+  unsigned long long ph_t0 = 0, ph_t1 = 0, ph_t2 = 0, ph_t3 = 0, ph_t4 = 0, ph_sum[4] = {0, 0, 0, 0};
+  int ph_tiles = 0;
+#endif
+  EKF_PHASE_STAMP(ph_t0);
   while (gemm_next_tile(g, &s_tile, iter, bi, bj)) {
+  EKF_PHASE_STAMP(ph_t1);
   const int grow0 = g.row_off + bi * TM, gcol0 = g.col_off + bj * TN;
   if (g.tri && grow0 + TM <= gcol0) continue;
   if (g.zrow && grow0 >= g.zrow && gcol0 >= g.zcol_end) continue;
@@ -449,6 +472,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmArgs g) {   // two wor
   store_tile(0);
   if (BK < K) load_tile(BK);
   __syncthreads();
+  EKF_PHASE_STAMP(ph_t2);
   read_frag(0, 0, 0);
   int stage = 0;
   for (int k0 = 0; k0 < K; k0 += BK, stage ^= 1) {
@@ -468,6 +492,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmArgs g) {   // two wor
       }
     }
   }
+  EKF_PHASE_STAMP(ph_t3);
   // epilogue: acc reg e of lane -> row (e&3) + 8*(e>>2) + 4*h, col l31 of the 32x32 tile
   const bool mirror = (TM == TN) && (g.tri == 2) && (grow0 >= gcol0 + TM);
 #pragma unroll
@@ -494,7 +519,21 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmArgs g) {   // two wor
         }
       }
     }
+#ifdef EKF_GEMM_STAMP
+  EKF_PHASE_STAMP(ph_t4);
+  ph_sum[0] += ph_t1 - ph_t0; ph_sum[1] += ph_t2 - ph_t1; ph_sum[2] += ph_t3 - ph_t2; ph_sum[3] += ph_t4 - ph_t3;
+  ++ph_tiles;
+  ph_t0 = ph_t4;
+#endif
   }  // tile loop
+#ifdef EKF_GEMM_STAMP
+  if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 1024) {
+    ekf_stamp_buf[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+    ekf_stamp_buf[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+    for (int q = 0; q < 4; ++q) ekf_phase_buf[8 * blockIdx.x + q] = ph_sum[q];
+    ekf_phase_buf[8 * blockIdx.x + 4] = ph_tiles;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
