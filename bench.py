@@ -104,6 +104,13 @@ class FilterRing:
                 out[k] = (a[0] + ms, a[1] + cnt)
         return out
 
+    def profile_work(self):
+        out = {}
+        for f in self.filters:
+            for k, w in f.profile_work().items():
+                out[k] = out.get(k, 0.0) + w
+        return out
+
     def synchronize(self):
         for f in self.filters:
             f.synchronize()
@@ -216,6 +223,7 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     prof = flt.profile()
+    work = flt.profile_work()
     flt.set_option(2, 0)
     elapsed = t1 - t0
     ms_per_step = 1e3 * elapsed / args.steps
@@ -232,18 +240,22 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
     roofline = None
     pieces = 1
     if syrk_cnt:
+        # the timed launches and their algorithmic flop come from the library (ekf_profile_read / ekf_profile_work):
+        # n^2 x the real columns of every downdate launch (symmetric half); with the default pipeline the
+        # first chunk's launch also carries that chunk's W update (2 (n+1)(m - c1) x its columns), counted with it.
         t_k = syrk_ms / syrk_cnt * 1e-3
-        pieces = max(1, round(syrk_cnt / args.steps))  # > 1 only with --pipeline 1 (column groups of V)
-        flop = float(n) * n * m / pieces              # symmetric-half rank-m downdate
+        pieces = max(1, round(syrk_cnt / args.steps))
+        flop = work.get("downdate_syrk", 0.0) / syrk_cnt
         ach = flop / t_k / 1e12
         roofline = {"kernel": "downdate_syrk (k_gemm_nt_mfma, f32 MFMA 32x32x2)", "bound": "mfma",
                     "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F32_MFMA_TF, 4), "traffic": None,
                     "avg_launch_ms": round(t_k * 1e3, 4), "launches": syrk_cnt,
                     "algorithmic_flop_per_launch": flop, "launches_per_step": pieces,
-                    "note": ("the downdate runs as %d column-group pieces per step on 224 of 256 CUs, overlapped with the "
-                             "serial Cholesky chain (EKF_OPT_PIPELINE); --pipeline 0 runs it as one launch" % pieces)
-                            if pieces > 1 else "one launch per step"}
+                    "note": ("%d launches per step (column chunks of V; all but the last on 224 of 256 CUs beside the "
+                             "serial Cholesky chain, EKF_OPT_PIPELINE; the first also carries its chunk's W update); "
+                             "--pipeline 0 runs one launch" % pieces)
+                            if pieces > 1 or args.pipeline != 0 else "one launch per step"}
 
     # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside bench.py)
     pmc_path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")

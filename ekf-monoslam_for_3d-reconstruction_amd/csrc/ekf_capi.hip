@@ -81,6 +81,7 @@ struct FilterBase {
   virtual int feature_xyz(int, void*, void*) = 0;
   virtual int profile_read(int, double*, long long*) = 0;
   virtual int profile_reset() = 0;
+  virtual int profile_work(int, double*) = 0;
   virtual void* dev_mu() = 0;
   virtual void* dev_sigma(int*) = 0;
   virtual int export_points(void*, int) = 0;
@@ -181,6 +182,7 @@ struct Filter : FilterBase {
   unsigned char* d_found = nullptr;
   float* d_score = nullptr;
   int* d_keep = nullptr;
+  int opt_fuse_wu = 1;                                  // EKF_FUSE_WU: 0 never, 1 every overlapped chunk but the one before the last, 2 every overlapped chunk
   int env_chunks[8] = {}, env_nchunks = 0;               // EKF_CHUNKS="5,10,14,16": tuning knob (block steps)
   int opt_pipeline = -1;                                 // -1 auto: on when the chain has >= 8 block steps
   int* d_tilemap = nullptr;                             // work lists: [lower-tri super-tiles | solve heavy-first]
@@ -197,6 +199,7 @@ struct Filter : FilterBase {
   std::vector<hipEvent_t> pool;
   double prof_ms[KID_COUNT];
   long long prof_cnt[KID_COUNT];
+  double prof_work[KID_COUNT];                          // algorithmic flop of the timed launches (downdate only)
 
   static constexpr bool kIsF32 = sizeof(T) == 4;
   int NB() const { return (kIsF32 && opt_mfma) ? 128 : 64; }
@@ -272,6 +275,7 @@ struct Filter : FilterBase {
     w_rows = n_pad + 128;
     memset(prof_ms, 0, sizeof(prof_ms));
     memset(prof_cnt, 0, sizeof(prof_cnt));
+    memset(prof_work, 0, sizeof(prof_work));
     cam.fx = c->fx; cam.fy = c->fy; cam.u0 = c->u0; cam.v0 = c->v0;
     cam.k1 = c->k1; cam.k2 = c->k2; cam.k3 = c->k3; cam.p1 = c->p1; cam.p2 = c->p2;
     cam.width = c->image_width; cam.height = c->image_height; cam.half_window = c->window_size / 2;
@@ -356,6 +360,7 @@ struct Filter : FilterBase {
         HIPCHK(hipStreamCreateWithFlags(&stream_c, hipStreamNonBlocking));
       }
       if (const char* e = getenv("EKF_CHAIN_MASK")) opt_chain_mask = atoi(e);
+      if (const char* e = getenv("EKF_FUSE_WU")) opt_fuse_wu = atoi(e);
       if (const char* e = getenv("EKF_CHUNKS")) {           // tuning knob: chunk ends in block steps
         for (const char* q = e; *q && env_nchunks < 8;) {
           env_chunks[env_nchunks++] = atoi(q);
@@ -1073,7 +1078,14 @@ struct Filter : FilterBase {
                                  0, 0, 1, 0, ss, list, wt * ntr);
         }
       }
-      if (c1 < m_pad) {
+      // W update and downdate of an overlapped chunk go out as ONE queued launch when both run on 128 x 128 tiles:
+      // they read the same V_g, and sharing a launch saves one ramp and one partially filled last round.  Not for
+      // the chunk before the last: the last solve starts on that chunk's W update, not on its downdate.
+      bool fuse = false;
+      if constexpr (kIsF32)
+        fuse = opt_fuse_wu && (opt_fuse_wu > 1 || gi + 2 < nchunks) && opt_mfma && overlap && c1 < m_pad &&
+               !opt_split_bf16 && tile == 128 && tri_count >= num_cus && counter_next < 64;
+      if (c1 < m_pad && !fuse) {
         Scope sc(this, KID_WUPDATE, ss);
         const int slots = 2 * (overlap ? num_cus - reserved_cus : num_cus);
         if (kIsF32 && opt_mfma && ((m_pad - c1) / 128) * ntr < slots)
@@ -1083,7 +1095,7 @@ struct Filter : FilterBase {
           gemm<ROLE_WUPDATE, false>(d_V + c0, ldy, Y + (size_t)c1 * ldy + c0, ldy, d_W + c1, ldy, npad_live + nb, m_pad - c1,
                                     width, T(-1), T(1), 0, 0, 0, 0, 0, ss);
       }
-      if (overlap && c1 < m_pad) HIPCHK(hipEventRecord(ev_wu, stream_b));
+      if (overlap && c1 < m_pad && !fuse) HIPCHK(hipEventRecord(ev_wu, stream_b));
       if (!overlap && b_inflight) {                  // earlier downdates must be done before Sigma is touched again
         HIPCHK(hipEventRecord(ev_b, stream_b));
         HIPCHK(hipStreamWaitEvent(stream, ev_b, 0));
@@ -1110,6 +1122,7 @@ struct Filter : FilterBase {
             k_split_bf16<<<grid, 256, 0, ss>>>(d_V, ldy, npad_live, c0, width, d_Vs[0], d_Vs[1], d_Vs[2]);
           }
           Scope sc(this, KID_DOWNDATE, ss);
+          if (sc.on) prof_work[KID_DOWNDATE] += double(n) * n * (std::min(c1, m) - std::min(c0, m));
           SplitArgs a{{d_Vs[0] + c0, d_Vs[1] + c0, d_Vs[2] + c0}, ldy, S(), ld, width, d_tilemap, tri_count,
                       d_counters + counter_next++};
           const int wgs = 2 * (overlap ? (num_cus - reserved_cus) : num_cus);
@@ -1117,8 +1130,24 @@ struct Filter : FilterBase {
           split_done = true;
         }
       }
-      if (!split_done) {
+      if (fuse) {
+        if constexpr (kIsF32) {
+          Scope sc(this, KID_DOWNDATE, ss);               // W[:, c1:] -= V_g L[c1:, g]^T, then Sigma -= V_g V_g^T
+          if (sc.on) {
+            const double w = std::min(c1, m) - std::min(c0, m);
+            prof_work[KID_DOWNDATE] += double(n) * n * w + 2.0 * (n + 1) * std::max(0, m - c1) * w;
+          }
+          const int nr2 = (npad_live + nb) / 128, n2 = nr2 * ((m_pad - c1) / 128);
+          GemmArgs g{d_V + c0, ldy, d_V + c0, ldy, S(), ld, width, -1.0, 1.0, 2, 0, 0, 0, 0,
+                     d_tilemap, n2 + tri_count, d_counters + counter_next++, 0, 0, 1,
+                     Y + (size_t)c1 * ldy + c0, ldy, d_W + c1, ldy, n2, nr2};
+          const int wgs = 2 * (num_cus - reserved_cus);
+          k_gemm_mfma<ROLE_DOWNDATE, false><<<std::min(g.ntiles, wgs), 256, 0, ss>>>(g);
+          HIPCHK(hipEventRecord(ev_wu, stream_b));
+        }
+      } else if (!split_done) {
         Scope sc(this, KID_DOWNDATE, ss);                 // Sigma -= V_g V_g^T (lower tiles + mirror)
+        if (sc.on) prof_work[KID_DOWNDATE] += double(n) * n * (std::min(c1, m) - std::min(c0, m));   // symmetric half, 2 flop per MAC
         if (kIsF32 && opt_mfma && tri_count < num_cus)    // small map: 64 x 64 tiles, or most of the chip idles
           gemm<ROLE_DOWNDATE, false, 64, 64>(d_V + c0, ldy, d_V + c0, ldy, S(), ld, npad_live, npad_live, width, T(-1), T(1),
                                              2, 0, 0, 0, 0, ss, d_tilemap + tri64_off, tri64_count);
@@ -1646,11 +1675,17 @@ struct Filter : FilterBase {
     if (cnt) *cnt = prof_cnt[kid];
     return EKF_OK;
   }
+  int profile_work(int kid, double* flop) override {
+    if (kid < 0 || kid >= KID_COUNT) FAIL(EKF_ERR_ARG, "kernel id out of range");
+    if (flop) *flop = prof_work[kid];
+    return EKF_OK;
+  }
   int profile_reset() override {
     hipSetDevice(device);
     resolve_profile();
     memset(prof_ms, 0, sizeof(prof_ms));
     memset(prof_cnt, 0, sizeof(prof_cnt));
+    memset(prof_work, 0, sizeof(prof_work));
     return EKF_OK;
   }
 };
@@ -1793,6 +1828,7 @@ int ekf_profile_kernels(void) { return ekf::KID_COUNT; }
 const char* ekf_profile_kernel_name(int kid) { return (kid >= 0 && kid < ekf::KID_COUNT) ? ekf::kKernelNames[kid] : ""; }
 int ekf_profile_read(ekf_filter* f, int kid, double* ms, long long* cnt) { IMPL_OR_ARG(f); return f->impl->profile_read(kid, ms, cnt); }
 int ekf_profile_reset(ekf_filter* f) { IMPL_OR_ARG(f); return f->impl->profile_reset(); }
+int ekf_profile_work(ekf_filter* f, int kid, double* flop) { IMPL_OR_ARG(f); return f->impl->profile_work(kid, flop); }
 
 int ekf_rescue_high_innovation(ekf_filter* f, const void* cam, const void* z, const int* idx, int M, double thr,
                                unsigned char* out) {

@@ -200,7 +200,15 @@ struct GemmArgs {
   const int* tile_map; int ntiles; int* counter;
   int zrow, zcol_end;
   int stagger;                                  // persistent grid: the second half of the workgroups starts `stagger` x 3.4 us late
+  // Optional second product in the same queued launch (k_gemm_mfma, ROLE_DOWNDATE): C2 -= A B2^T over a plain
+  // nr2 x (n2 / nr2) grid of tiles, same A, K, alpha and beta.  Its n2 tiles are drawn first (queue indices
+  // 0 .. n2-1, column-major), the tile_map entries after them: the W update of a chunk and its downdate share one
+  // ramp and one tail instead of two.
+  const void* B2; int ldb2;
+  void* C2; int ldc2;
+  int n2, nr2;
 };
+constexpr int kSecondProduct = 0x10000;         // flag on bj for a tile of the second product
 
 // Next tile of this workgroup: plain 2-D grid (one tile, then done) or the work queue.
 __device__ __forceinline__ bool gemm_next_tile(const GemmArgs& g, int* s_tile, int& iter, int& bi, int& bj) {
@@ -215,8 +223,13 @@ __device__ __forceinline__ bool gemm_next_tile(const GemmArgs& g, int* s_tile, i
   __syncthreads();
   const int t = *s_tile;
   if (t >= g.ntiles) return false;
-  bi = g.tile_map[2 * t];
-  bj = g.tile_map[2 * t + 1];
+  if (t < g.n2) {
+    bi = t % g.nr2;
+    bj = (t / g.nr2) | kSecondProduct;
+  } else {
+    bi = g.tile_map[2 * (t - g.n2)];
+    bj = g.tile_map[2 * (t - g.n2) + 1];
+  }
   ++iter;
   return true;
 }
@@ -325,9 +338,10 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmArgs g) {   // two wor
   constexpr int BK = 32, NQ = BK / 4, MI = TM / 64, NJ = TN / 64, PA = TM / 32, PB = TN / 32;
   static_assert((TM == 64 || TM == 128) && (TN == 64 || TN == 128), "tile shape");
   const float* A = static_cast<const float*>(g.A);
-  const float* B = static_cast<const float*>(g.B);
-  float* C = static_cast<float*>(g.C);
-  const int lda = g.lda, ldb = g.ldb, ldc = g.ldc;
+  const float* B0 = static_cast<const float*>(g.B);
+  float* C0 = static_cast<float*>(g.C);
+  const int lda = g.lda;
+  constexpr bool DUAL = (ROLE == ROLE_DOWNDATE) && !BT && TM == 128 && TN == 128;   // GemmArgs::B2 / C2
   const float alpha = float(g.alpha), beta = float(g.beta);
   __shared__ f32x4 lds[2 * NQ * (TM + TN)];   // two stages of {A image, B image}: one barrier per K step
   __shared__ int s_tile;
@@ -350,8 +364,14 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmArgs g) {   // two wor
   EKF_PHASE_STAMP(ph_t0);
   while (gemm_next_tile(g, &s_tile, iter, bi, bj)) {
   EKF_PHASE_STAMP(ph_t1);
+  const bool second = DUAL && (bj & kSecondProduct);
+  if (DUAL) bj &= kSecondProduct - 1;
+  const float* B = second ? static_cast<const float*>(g.B2) : B0;
+  float* C = second ? static_cast<float*>(g.C2) : C0;
+  const int ldb = second ? g.ldb2 : g.ldb, ldc = second ? g.ldc2 : g.ldc;
+  const int tri = second ? 0 : g.tri;
   const int grow0 = g.row_off + bi * TM, gcol0 = g.col_off + bj * TN;
-  if (g.tri && grow0 + TM <= gcol0) continue;
+  if (tri && grow0 + TM <= gcol0) continue;
   if (g.zrow && grow0 >= g.zrow && gcol0 >= g.zcol_end) continue;
   const int K = g.ktri ? min(g.K, (bj + g.ktile_off + 1) * TN) : g.K;
   // A staging: TM*8 float4 per tile, PA per lane; 8 consecutive lanes cover 128 B of a row
@@ -494,7 +514,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmArgs g) {   // two wor
   }
   EKF_PHASE_STAMP(ph_t3);
   // epilogue: acc reg e of lane -> row (e&3) + 8*(e>>2) + 4*h, col l31 of the 32x32 tile
-  const bool mirror = (TM == TN) && (g.tri == 2) && (grow0 >= gcol0 + TM);
+  const bool mirror = (TM == TN) && (tri == 2) && (grow0 >= gcol0 + TM);
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll

@@ -332,6 +332,16 @@ class VSlamFilter:
                 out[self._lib.ekf_profile_kernel_name(k).decode()] = (ms.value, cnt.value)
         return out
 
+    def profile_work(self):
+        """Algorithmic flop of the launches timed under each kernel name (kept for "downdate_syrk")."""
+        out = {}
+        for k in range(self._lib.ekf_profile_kernels()):
+            w = C.c_double()
+            self._check(self._lib.ekf_profile_work(self._h, k, C.byref(w)))
+            if w.value:
+                out[self._lib.ekf_profile_kernel_name(k).decode()] = w.value
+        return out
+
     def profile_reset(self):
         self._check(self._lib.ekf_profile_reset(self._h))
 

@@ -240,6 +240,10 @@ int ekf_profile_kernels(void);
 const char* ekf_profile_kernel_name(int kernel_id);
 int ekf_profile_read(ekf_filter* f, int kernel_id, double* total_ms, long long* launches);
 int ekf_profile_reset(ekf_filter* f);
+/* Algorithmic flop of the launches timed under `kernel_id` since the last reset (kept for "downdate_syrk" only:
+ * n^2 x the real columns of the chunk (symmetric half), plus 2 (n+1) (m - c1) x those columns where the launch also
+ * carries the W update of its chunk). */
+int ekf_profile_work(ekf_filter* f, int kernel_id, double* flop);
 
 /* ---- multi-GPU: row-panel sharding, one process per GPU --------------------
  * Every rank holds the same feature list; rank g owns features [N g/G, N (g+1)/G) and keeps the
