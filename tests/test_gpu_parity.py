@@ -506,6 +506,32 @@ def test_mid_size_chunked_equals_serial(n_feat, m_meas, plane):
     assert np.abs(S_a - S_a.T).max() <= 1e-6 * np.abs(S_a).max()
 
 
+def test_fused_wupdate_launch_is_bit_identical(monkeypatch):
+    """The W update of a chunk riding in its downdate launch (EKF_FUSE_WU, default: first chunk) runs the same tiles
+    with the same per-tile arithmetic as two launches: mu and Sigma must agree to the last bit."""
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from ekf_monoslam_amd import synthetic
+    cfg = pkg.kinect_config()
+    n_feat = 640                                             # 10 block steps, chunks 3 / 6 / 10, 465 lower tiles >= 256 CUs
+    px0, z = synthetic.measurement_stream(cfg, n_feat, 3, sigma_px=0.5)
+    idx = np.arange(n_feat, dtype=np.int32)
+    outs = []
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("EKF_FUSE_WU", mode)              # read when the filter is created
+        f = pkg.VSlamFilter(cfg, capacity_features=n_feat)
+        f.setDt(1.0 / 30.0)
+        for (u, v) in px0:
+            assert f.addFeature((u, v)) == 1
+        for k in range(2):
+            f.predict()
+            f.update(z[k].reshape(-1), idx)
+        f.synchronize()
+        outs.append((f.getFullState(), f.getFullSigma()))
+    for mu, S in outs[1:]:
+        assert np.array_equal(mu, outs[0][0]) and np.array_equal(S, outs[0][1])
+
+
 def test_largest_config_n4000_properties():
     """BASELINE configs[4] size on one GPU (N = M = 4000, n = 24014, 63 block steps, 2 x 2.3 GB of Sigma):
     one predict + update + a resize; the same size-independent properties as the N = 1000 test."""
