@@ -182,6 +182,7 @@ struct Filter : FilterBase {
   unsigned char* d_found = nullptr;
   float* d_score = nullptr;
   int* d_keep = nullptr;
+  int opt_panel_direct = 1;                             // EKF_PANEL_DIRECT=0: panel through the general tile GEMM
   int opt_fuse_wu = 1;                                  // EKF_FUSE_WU: 0 never, 1 every overlapped chunk but the one before the last, 2 every overlapped chunk
   int env_chunks[8] = {}, env_nchunks = 0;               // EKF_CHUNKS="5,10,14,16": tuning knob (block steps)
   int opt_pipeline = -1;                                 // -1 auto: on when the chain has >= 8 block steps
@@ -361,6 +362,7 @@ struct Filter : FilterBase {
       }
       if (const char* e = getenv("EKF_CHAIN_MASK")) opt_chain_mask = atoi(e);
       if (const char* e = getenv("EKF_FUSE_WU")) opt_fuse_wu = atoi(e);
+      if (const char* e = getenv("EKF_PANEL_DIRECT")) opt_panel_direct = atoi(e);
       if (const char* e = getenv("EKF_CHUNKS")) {           // tuning knob: chunk ends in block steps
         for (const char* q = e; *q && env_nchunks < 8;) {
           env_chunks[env_nchunks++] = atoi(q);
@@ -808,6 +810,18 @@ struct Filter : FilterBase {
     k_gemm_valu<T, ROLE, BT><<<grid, 256, 0, st>>>(g);
   }
 
+  // Panel of a chain step: P <- P Linv_jj^T in place (vrows rows, block nb).
+  void launch_panel(T* P, const T* Dj, int vrows, hipStream_t st) {
+    const int nb = NB();
+    if constexpr (kIsF32) {
+      if (opt_mfma && nb == 128 && opt_panel_direct) {
+        k_panel_direct<<<(vrows + 63) / 64, 256, 0, st>>>(P, ldy, Dj, vrows);
+        return;
+      }
+    }
+    gemm<ROLE_PANEL, false, 64, 128>(P, ldy, Dj, nb, P, ldy, vrows, nb, nb, T(1), T(0), 0, 0, 0, 0, 0, st);
+  }
+
   // Work lists for the queued GEMMs: (1) lower-triangular tiles of an nt x nt grid in 8x8
   // super-tiles; (2) the ntr x ntc tiles of the triangular solve, heaviest (largest bj) first.
   int ensure_tilemap(int nt, int ntr, int ntc) {
@@ -1034,7 +1048,7 @@ struct Filter : FilterBase {
         {
           Scope sc(this, KID_CHOL_PANEL, sc_);                 // P = Y[r0.., j:j+nb] * Linv_jj^T, in place
           T* P = Y + (size_t)r0 * ldy + j;
-          gemm<ROLE_PANEL, false, 64, 128>(P, ldy, Dj, nb, P, ldy, vrows, nb, nb, T(1), T(0), 0, 0, 0, 0, 0, sc_);
+          launch_panel(P, Dj, vrows, sc_);
         }
         if (r0 < m_pad) {
           Scope sc(this, KID_CHOL_TRAILING, sc_);              // Y[r0.., r0:] -= P P_S^T; strip rows stop at c1
@@ -1591,7 +1605,7 @@ struct Filter : FilterBase {
         const int vrows = m_pad - c0;
         { Scope sc(this, KID_CHOL_PANEL);
           T* P = Y + (size_t)r0 * ldy + j;
-          gemm<ROLE_PANEL, false, 64, 128>(P, ldy, Dj, nb, P, ldy, vrows, nb, nb, T(1), T(0), 0, 0, 0, 0); }
+          launch_panel(P, Dj, vrows, stream); }
         if (r0 < m_pad) {
           Scope sc(this, KID_CHOL_TRAILING);
           const T* P = Y + (size_t)r0 * ldy + j;

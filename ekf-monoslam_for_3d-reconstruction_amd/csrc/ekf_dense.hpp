@@ -1059,6 +1059,81 @@ k_chol_diag_packed(float* __restrict__ Aglob, int ld, float* __restrict__ Dinv, 
 }
 
 // ---------------------------------------------------------------------------------------
+// Panel of a chain step (f32, block 128), in place: P <- P Linv^T for `rows` rows of P (row stride ldp), Linv the
+// 128 x 128 lower-triangular inverse k_chol_diag_packed left in Dinv (row-major, stride 128).
+// One workgroup = 64 rows, one wave = 16 rows x all 128 columns: the wave's A fragments (its own rows, all of K)
+// go from global memory into registers before its first store, so the update is in place without a barrier
+// between reading and writing; Linv is staged once per workgroup in LDS (row pitch 33 x 16 bytes: the 16 lanes of
+// a ds_read_b128 group hit 16 different bank groups).  v_mfma_f32_16x16x4_f32; lane (lr, lq) of MFMA step (u, e)
+// multiplies k = 16 u + 4 lq + e on both operands; column tile ct only needs k < 16 (ct + 1) (Linv is lower
+// triangular): 144 MFMAs per wave instead of 256.  Replaces the 64 x 128 tile-GEMM launch of the general kernel
+// (K = 128 is four of its K steps: prologue, epilogue and barriers dominated).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2) k_panel_direct(float* __restrict__ P, int ldp, const float* __restrict__ Dinv, int rows) {
+  constexpr int NB = 128, PITCH = 132;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __shared__ float sl[NB * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  __builtin_amdgcn_s_setprio(2);                 // part of the serial chain
+  const int row0 = blockIdx.x * 64 + wave * 16;
+  const bool live = row0 < rows;
+  // the wave's rows: A[row0 + lr][16 u + 4 lq ..]
+  f4 fa[8];
+  float* Prow = P + (size_t)(row0 + lr) * ldp;
+  if (live) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) fa[u] = *reinterpret_cast<const f4*>(Prow + 16 * u + 4 * lq);
+  }
+  // Linv in two halves: rows 0..63 (their columns 0..63: 1024 float4) are staged first and feed column tiles 0..3;
+  // rows 64..127 (2048 float4) travel under those MFMAs and feed column tiles 4..7
+  f4 v0[4], v1[8];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int q = tid + 256 * p;                 // row q / 16, columns 4 (q % 16) ..
+    v0[p] = *reinterpret_cast<const f4*>(Dinv + (size_t)(q >> 4) * NB + 4 * (q & 15));
+  }
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int q = tid + 256 * p;                 // row 64 + q / 32, columns 4 (q % 32) ..
+    v1[p] = *reinterpret_cast<const f4*>(Dinv + (size_t)(64 + (q >> 5)) * NB + 4 * (q & 31));
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int q = tid + 256 * p;
+    *reinterpret_cast<f4*>(sl + (q >> 4) * PITCH + 4 * (q & 15)) = v0[p];
+  }
+  __syncthreads();
+  auto column_tiles = [&](int ct0) {
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      const int ct = ct0 + c4;
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float* bl = sl + (16 * ct + lr) * PITCH + 4 * lq;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (u <= ct) {
+          const f4 fb = *reinterpret_cast<const f4*>(bl + 16 * u);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][e], fb[e], acc, 0, 0, 0);
+        }
+      }
+      // acc[e] = P'[row0 + 4 lq + e][16 ct + lr]
+#pragma unroll
+      for (int e = 0; e < 4; ++e) P[(size_t)(row0 + 4 * lq + e) * ldp + 16 * ct + lr] = acc[e];
+    }
+  };
+  if (live) column_tiles(0);
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int q = tid + 256 * p;
+    *reinterpret_cast<f4*>(sl + (64 + (q >> 5)) * PITCH + 4 * (q & 31)) = v1[p];
+  }
+  __syncthreads();
+  if (live) column_tiles(4);
+}
+
+// ---------------------------------------------------------------------------------------
 // mu[i] += sum_c V[i][c] y[c]   (K nu = V (L^-1 nu)); one wave per row.
 // ---------------------------------------------------------------------------------------
 template <typename T>
