@@ -915,45 +915,65 @@ __device__ __forceinline__ void diag_tile_update(float* a, int LDA, int prow0, i
   for (int e = 0; e < 4; ++e) a[(prow0 + 4 * lq + e) * LDA + c0 + lr] = acc[e];
 }
 
-// 16x16 factor + inverse of the diagonal block at K0, in the registers of ONE wave (rows broadcast
-// with v_readlane): writes L16 (lower), Z16 = X16^T (strict upper), 1/diag and X16.
+// 16x16 factor + inverse of the diagonal block at K0 in ONE wave, on the matrix pipe: writes L16 (lower),
+// Z16 = X16^T (strict upper), 1/diag and X16 = L16^-1.
+// The block lives in the C layout of v_mfma_f32_16x16x4_f32 (lane (lr, lq), register e = element [4 lq + e][lr]),
+// BOTH triangles, and so does X (identity at the start).  Column k (slot s = k / 4, e = k % 4): row k of the
+// symmetric block sits in the 16 lanes of group lq = s, register e -- exactly where an MFMA reads k-slot s of its
+// A operand (A[i = lr][s]) and of its B operand (B[s][j = lr]).  With pk = a[k][k] (one v_readlane), inv = rsq(pk):
+//   v = row k * inv for lr >= k, else 0            = column k of L
+//   block -= v v^T                                  one MFMA (right-looking elimination of the whole block)
+//   X     -= w (row k of X),  w = (v - e_k) * inv   one MFMA (X <- L_k^-1 X, L_k = I + (v - e_k) e_k^T)
+// i.e. 2 MFMAs + ~8 VALU per column instead of 15 broadcasts + 15 FMAs for L and as many again for X: the
+// dependent chain readlane -> rsq -> scale -> MFMA is what a column costs.
 // (A substitution panel that needs no X16 was measured slower: 1.7 us per step against 0.2 us for
 // the MFMA panel + 1.15 us for the inverse.)
 __device__ __forceinline__ void diag_factor16(float* a, int LDA, int K0, float* x16, float* rinv, int lane,
                                               int* status) {
-  const int i = lane & 15;
-  float r[16], inv[16];
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int lr = lane & 15, lq = lane >> 4;
+  f4 acc, xac;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) r[j] = (j <= i) ? a[(K0 + i) * LDA + K0 + j] : 0.f;
+  for (int e = 0; e < 4; ++e) {
+    const int r = 4 * lq + e;
+    acc[e] = a[(K0 + max(r, lr)) * LDA + K0 + min(r, lr)];     // the LDS image holds the lower triangle
+    xac[e] = (r == lr) ? 1.f : 0.f;
+  }
   bool bad = false;
-  // X = L16^-1 is built in the same sweep (lane c holds column c: x[ii] = X[ii][c]): row ii of X only needs
-  // row ii of L (final once step ii-1 is done) and 1 / L[ii][ii], so its dot products fill the issue slots the
-  // dependent pivot -> rsq -> scale -> broadcast chain of the factorisation leaves empty.
-  float x[16];
+  float lcol[16], inv[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    const float pk = lane_bcast(r[k], k);
+    const int s = k >> 2, e = k & 3;
+    // the dependent chain of a column: MFMA -> v_readlane -> v_rsq -> v_mul -> MFMA; everything else is off it
+    const bool low = (lq == s) && (lr >= k);
+    const float am = low ? acc[e] : 0.f;                   // row k of the block where it is column k of L
+    const float pk = lane_bcast(acc[e], 16 * s + k);
+    const float iv = __frsqrt_rn(pk);                      // (a pivot <= 0 gives NaN / inf: flagged, the caller fails)
+    const float v = am * iv, nv = -am * iv;                // L[lr][k]; lr == k: pk * rsq(pk) = sqrt(pk)
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(nv, v, acc, 0, 0, 0);
     if (!(pk > 0.f)) bad = true;
-    inv[k] = __frsqrt_rn(pk > 0.f ? pk : 1.f);
-    float acc = 0.f;                             // row k of X: -inv[k] * sum_{t<k} L[k][t] X[t][c]
-#pragma unroll
-    for (int t = 0; t < k; ++t) acc += lane_bcast(r[t], k) * x[t];
-    const float lik = r[k] * inv[k];             // row k: pk * rsqrt(pk) = sqrt(pk)
-    r[k] = lik;
-#pragma unroll
-    for (int j = k + 1; j < 16; ++j) r[j] -= lik * lane_bcast(lik, j);
-    x[k] = (k == i) ? inv[k] : -inv[k] * acc;
-    if (k < i) x[k] = 0.f;
+    const float gt = ((lq == s) && (lr > k)) ? 1.f : 0.f, eq = ((lq == s) && (lr == k)) ? 1.f : 0.f;
+    const float nw = -(gt * v * iv + eq * (1.f - iv));     // -(v - e_k) / l_kk
+    const float xr = (lq == s) ? xac[e] : 0.f;
+    xac = __builtin_amdgcn_mfma_f32_16x16x4f32(nw, xr, xac, 0, 0, 0);
+    lcol[k] = v;
+    inv[k] = iv;
   }
   if (bad && lane == 0) status[0] = 1;
-  if (lane < 16) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      if (j <= i) a[(K0 + i) * LDA + K0 + j] = r[j];        // L16
-      else a[(K0 + i) * LDA + K0 + j] = x[j];               // Z16[i][j] = X[j][i]
-      x16[j * 17 + i] = x[j];                               // X16[j][i]
-    }
-    rinv[i] = inv[i];
+  for (int k = 0; k < 16; ++k)
+    if (lq == (k >> 2) && lr >= k) a[(K0 + lr) * LDA + K0 + k] = lcol[k];            // L16
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int r = 4 * lq + e;                                                         // xac[e] = X[r][lr]
+    if (r > lr) a[(K0 + lr) * LDA + K0 + r] = xac[e];                                 // Z16[lr][r] = X[r][lr]
+    x16[r * 17 + lr] = xac[e];
+  }
+  if (lane < 16) {
+    float iv = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) iv = (lane == k) ? inv[k] : iv;
+    rinv[lane] = iv;
   }
 }
 
