@@ -941,39 +941,54 @@ __device__ __forceinline__ void diag_factor16(float* a, int LDA, int K0, float* 
   }
   bool bad = false;
   float lcol[16], inv[16];
+  float pk = lane_bcast(acc[0], 0);
+  // X <- L_k^-1 X for column k: one MFMA, issued XLAG columns behind the elimination -- a wave issues in order, and
+  // an X update waiting for the previous X update would hold back the next elimination step
+  constexpr int XLAG = 3;
+  auto x_update = [&](int k) {
+    const int s = k >> 2, e = k & 3;
+    // -(v - e_k) / l_kk: v is already 0 outside rows >= k of group s
+    const float nw = ((lq == s) && (lr == k)) ? inv[k] - 1.f : -lcol[k] * inv[k];
+    const float xr = (lq == s) ? xac[e] : 0.f;
+    xac = __builtin_amdgcn_mfma_f32_16x16x4f32(nw, xr, xac, 0, 0, 0);
+  };
+  // the L16 store of a column goes out unconditionally: lanes that hold no element of it aim at the pad word of a
+  // row of the image (column 128: never read) -- no exec-mask branch per store
+  const int junk = lane * LDA + 128;
+  float my_inv = 0.f;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     const int s = k >> 2, e = k & 3;
-    // the dependent chain of a column: MFMA -> v_readlane -> v_rsq -> v_mul -> MFMA; everything else is off it
+    // The dependent chain of a column: v_rsq -> v_mul -> MFMA, with the NEXT pivot computed beside the MFMA from the
+    // operands it is about to consume: a[k+1][k+1] - L[k+1][k]^2 (two readlanes, one FMA), so that its rsq is ready
+    // when the MFMA result arrives.  Everything else (the X update, the stores, the flags) is off the chain.
     const bool low = (lq == s) && (lr >= k);
     const float am = low ? acc[e] : 0.f;                   // row k of the block where it is column k of L
-    const float pk = lane_bcast(acc[e], 16 * s + k);
     const float iv = __frsqrt_rn(pk);                      // (a pivot <= 0 gives NaN / inf: flagged, the caller fails)
-    const float v = am * iv, nv = -am * iv;                // L[lr][k]; lr == k: pk * rsq(pk) = sqrt(pk)
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(nv, v, acc, 0, 0, 0);
     if (!(pk > 0.f)) bad = true;
-    const float gt = ((lq == s) && (lr > k)) ? 1.f : 0.f, eq = ((lq == s) && (lr == k)) ? 1.f : 0.f;
-    const float nw = -(gt * v * iv + eq * (1.f - iv));     // -(v - e_k) / l_kk
-    const float xr = (lq == s) ? xac[e] : 0.f;
-    xac = __builtin_amdgcn_mfma_f32_16x16x4f32(nw, xr, xac, 0, 0, 0);
+    const float v = am * iv, nv = -am * iv;                // L[lr][k]; lr == k: pk * rsq(pk) = sqrt(pk)
+    if (k < 15) {
+      const int s1 = (k + 1) >> 2, e1 = (k + 1) & 3;
+      const float l10 = lane_bcast(v, 16 * s + k + 1);             // L[k+1][k]
+      const float a11 = lane_bcast(acc[e1], 16 * s1 + k + 1);      // a[k+1][k+1] before this column's update
+      pk = __builtin_fmaf(-l10, l10, a11);
+    }
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(nv, v, acc, 0, 0, 0);
     lcol[k] = v;
     inv[k] = iv;
+    a[low ? (K0 + lr) * LDA + K0 + k : junk] = v;          // L16
+    my_inv = (lr == k) ? iv : my_inv;
+    if (k >= XLAG) x_update(k - XLAG);
   }
-  if (bad && lane == 0) status[0] = 1;
 #pragma unroll
-  for (int k = 0; k < 16; ++k)
-    if (lq == (k >> 2) && lr >= k) a[(K0 + lr) * LDA + K0 + k] = lcol[k];            // L16
+  for (int k = 16 - XLAG; k < 16; ++k) x_update(k);
+  if (bad && lane == 0) status[0] = 1;
+  if (lane < 16) rinv[lane] = my_inv;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int r = 4 * lq + e;                                                         // xac[e] = X[r][lr]
     if (r > lr) a[(K0 + lr) * LDA + K0 + r] = xac[e];                                 // Z16[lr][r] = X[r][lr]
     x16[r * 17 + lr] = xac[e];
-  }
-  if (lane < 16) {
-    float iv = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) iv = (lane == k) ? inv[k] : iv;
-    rinv[lane] = iv;
   }
 }
 
