@@ -1053,7 +1053,8 @@ k_chol_diag_packed(float* __restrict__ Aglob, int ld, float* __restrict__ Dinv, 
       const int prow0 = top ? (K0 + 16 + wave * 16) : ((wave - nbelow) * 16);
       diag_tile_update(a, LDA, prow0, K0 + 16, K0, !top && (wave - nbelow) == b, rb_inv, lr, lq);
     }
-    __syncthreads();
+    // (no barrier here: wave 0's urgent tile IS the next diagonal tile, which only wave 0 goes on to read -- LDS
+    // operations of one wave execute in order --, and the remaining updates touch block columns b+2.. only)
     // (1') wave 0 factors block b+1 while waves 1.. apply the rest of update b (block columns b+2..)
     if (wave == 0) {
       if (MASK & 1) diag_factor16(a, LDA, K0 + 16, x16[(b + 1) & 1], rinv[(b + 1) & 1], lane, status);
