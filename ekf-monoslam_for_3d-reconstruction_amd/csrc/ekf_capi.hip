@@ -876,9 +876,10 @@ struct Filter : FilterBase {
       return env_nchunks;
     }
     if (opt_pipeline < 2) {
-      // default: three chunks ending at 4/16, 9/16 and 1 of the chain (tools/sweep_chunks.sh: the first chunk is
-      // exposed, so it is short; every further chunk re-reads Sigma once in its downdate, so there are few)
-      static const int kEnd16[3] = {4, 9, 16};
+      // default: three chunks ending at 3/16, 8/16 and 1 of the chain (tools/sweep_chunks.sh: the first chunk is
+      // exposed, so it is short; every further chunk re-reads Sigma once in its downdate, so there are few; with the
+      // chain at ~47 us per step the second stream, not the chain, decides where the last chunk may start)
+      static const int kEnd16[3] = {3, 8, 16};
       int k = 0, prev = 0;
       for (int g = 0; g < 3; ++g) {
         int e = (g == 2) ? nsteps : (nsteps * kEnd16[g] + 8) / 16;
