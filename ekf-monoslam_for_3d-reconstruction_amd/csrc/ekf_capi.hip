@@ -183,6 +183,7 @@ struct Filter : FilterBase {
   float* d_score = nullptr;
   int* d_keep = nullptr;
   int opt_panel_direct = 1;                             // EKF_PANEL_DIRECT=0: panel through the general tile GEMM
+  int opt_xcd_queues = 0;                               // EKF_XCD_QUEUES=1: one queue head per XCD for the downdate launches (HBM traffic 561 -> 467 MB per launch, step time +0.6 %: off)
   int opt_fuse_wu = 1;                                  // EKF_FUSE_WU: 0 never, 1 every overlapped chunk but the one before the last, 2 every overlapped chunk
   int env_chunks[8] = {}, env_nchunks = 0;               // EKF_CHUNKS="5,10,14,16": tuning knob (block steps)
   int opt_pipeline = -1;                                 // -1 auto: on when the chain has >= 8 block steps
@@ -330,7 +331,8 @@ struct Filter : FilterBase {
     HIPCHK(hipMalloc(&d_status, 4 * sizeof(int)));
     HIPCHK(hipMemsetAsync(d_status, 0, 4 * sizeof(int), stream));
     HIPCHK(hipMalloc(&d_tmp, 64 * sizeof(T)));
-    HIPCHK(hipMalloc(&d_counters, 64 * sizeof(int)));
+    HIPCHK(hipMalloc(&d_counters, kQueueCounters * sizeof(int)));
+    HIPCHK(hipMemset(d_counters, 0, kQueueCounters * sizeof(int)));
     {
       hipDeviceProp_t prop;
       HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -362,6 +364,7 @@ struct Filter : FilterBase {
       }
       if (const char* e = getenv("EKF_CHAIN_MASK")) opt_chain_mask = atoi(e);
       if (const char* e = getenv("EKF_FUSE_WU")) opt_fuse_wu = atoi(e);
+      if (const char* e = getenv("EKF_XCD_QUEUES")) opt_xcd_queues = atoi(e);
       if (const char* e = getenv("EKF_PANEL_DIRECT")) opt_panel_direct = atoi(e);
       if (const char* e = getenv("EKF_CHUNKS")) {           // tuning knob: chunk ends in block steps
         for (const char* q = e; *q && env_nchunks < 8;) {
@@ -786,10 +789,12 @@ struct Filter : FilterBase {
     if (!st) st = stream;
     const bool mf = kIsF32 && opt_mfma;
     dim3 grid(cols / (mf ? TN : 64), rows / (mf ? TM : 64));
-    if (tile_list && counter_next < 64) {
+    if (tile_list && counter_next + 8 <= kQueueCounters) {
       g.tile_map = tile_list;
       g.ntiles = ntiles;
-      g.counter = d_counters + counter_next++;
+      g.counter = d_counters + counter_next;
+      counter_next += 8;
+      g.xcd_queues = (ROLE == ROLE_DOWNDATE) ? opt_xcd_queues : 0;
       // persistent grid: two workgroups per CU the stream may use
       const bool side = (st == stream_b);
       const int wgs = 2 * (side ? (num_cus - reserved_cus) : num_cus);
@@ -1099,7 +1104,7 @@ struct Filter : FilterBase {
       bool fuse = false;
       if constexpr (kIsF32)
         fuse = opt_fuse_wu && (opt_fuse_wu > 1 || gi + 2 < nchunks) && opt_mfma && overlap && c1 < m_pad &&
-               !opt_split_bf16 && tile == 128 && tri_count >= num_cus && counter_next < 64;
+               !opt_split_bf16 && tile == 128 && tri_count >= num_cus && counter_next + 8 <= kQueueCounters;
       if (c1 < m_pad && !fuse) {
         Scope sc(this, KID_WUPDATE, ss);
         const int slots = 2 * (overlap ? num_cus - reserved_cus : num_cus);
@@ -1154,8 +1159,9 @@ struct Filter : FilterBase {
           }
           const int nr2 = (npad_live + nb) / 128, n2 = nr2 * ((m_pad - c1) / 128);
           GemmArgs g{d_V + c0, ldy, d_V + c0, ldy, S(), ld, width, -1.0, 1.0, 2, 0, 0, 0, 0,
-                     d_tilemap, n2 + tri_count, d_counters + counter_next++, 0, 0, 1,
-                     Y + (size_t)c1 * ldy + c0, ldy, d_W + c1, ldy, n2, nr2};
+                     d_tilemap, n2 + tri_count, d_counters + counter_next, 0, 0, 1,
+                     Y + (size_t)c1 * ldy + c0, ldy, d_W + c1, ldy, n2, nr2, opt_xcd_queues};
+          counter_next += 8;
           const int wgs = 2 * (num_cus - reserved_cus);
           k_gemm_mfma<ROLE_DOWNDATE, false><<<std::min(g.ntiles, wgs), 256, 0, ss>>>(g);
           HIPCHK(hipEventRecord(ev_wu, stream_b));

@@ -17,12 +17,14 @@ namespace ekf {
 // ---------------------------------------------------------------------------------------
 // nu = z - h for the measured list (+ plane rows: 0 - mu[{1,4,6}], vR.cpp:1257-1260).
 // ---------------------------------------------------------------------------------------
+constexpr int kQueueCounters = 256;              // 8 heads (one per XCD) x up to 32 queued launches per update
+
 template <typename T>
 __global__ void k_innovation(const T* __restrict__ z, const T* __restrict__ h, const int* __restrict__ midx,
                              int M, int plane, const T* __restrict__ mu, T* __restrict__ nu, int m_pad,
                              int* __restrict__ counters) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (counters && t < 64) counters[t] = 0;          // work-queue heads of this update's queued GEMMs
+  if (counters && t < kQueueCounters) counters[t] = 0;   // work-queue heads of this update's queued GEMMs
   if (t >= m_pad) return;
   T v = T(0);
   if (t < 2 * M) {
@@ -207,6 +209,11 @@ struct GemmArgs {
   const void* B2; int ldb2;
   void* C2; int ldc2;
   int n2, nr2;
+  // XCD-aware queue (xcd_queues != 0; counter then points at 8 heads): the list is cut into 8 equal runs, run q
+  // served first to the workgroups of XCD q (workgroup w runs on XCD w % 8); a workgroup whose run is exhausted
+  // moves on to the next runs.  The tiles in flight on an XCD are then neighbours in the list -- a super-tile of the
+  // downdate -- and share their operand panels in that XCD's L2 instead of fetching them into all eight.
+  int xcd_queues;
 };
 constexpr int kSecondProduct = 0x10000;         // flag on bj for a tile of the second product
 
@@ -219,7 +226,21 @@ __device__ __forceinline__ bool gemm_next_tile(const GemmArgs& g, int* s_tile, i
     return true;
   }
   __syncthreads();                       // everyone is done with the previous tile (and s_tile)
-  if (threadIdx.x == 0) *s_tile = atomicAdd(g.counter, 1);
+  if (threadIdx.x == 0) {
+    int t = g.ntiles;
+    if (!g.xcd_queues) {
+      t = atomicAdd(g.counter, 1);
+    } else {
+      const int q0 = blockIdx.x & 7;
+      for (int d = 0; d < 8; ++d) {
+        const int q = (q0 + d) & 7;
+        const int lo = (int)((long long)g.ntiles * q / 8), hi = (int)((long long)g.ntiles * (q + 1) / 8);
+        const int i = atomicAdd(g.counter + q, 1);
+        if (lo + i < hi) { t = lo + i; break; }
+      }
+    }
+    *s_tile = t;
+  }
   __syncthreads();
   const int t = *s_tile;
   if (t >= g.ntiles) return false;
