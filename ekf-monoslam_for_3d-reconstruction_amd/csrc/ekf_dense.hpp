@@ -1239,37 +1239,68 @@ __device__ __forceinline__ void diag_tile_update_f64(double* a, int LDA, int pro
   for (int e = 0; e < 4; ++e) a[(prow0 + 4 * e + lq) * LDA + c0 + lr] = acc[e];
 }
 
+// fp64 twin of diag_factor16 on v_mfma_f64_16x16x4_f64, whose C layout differs: lane (lr, lq), register e = element
+// [4 e + lq][lr].  Row k of the symmetric block therefore sits in the 16 lanes of group lq = k % 4, register k / 4 --
+// again where an MFMA reads one k-slot of its A and of its B operand.
 __device__ __forceinline__ void diag_factor16_f64(double* a, int LDA, int K0, double* x16, double* rinv, int lane,
                                                   int* status) {
-  const int i = lane & 15;
-  double r[16], inv[16], x[16];
+  const int lr = lane & 15, lq = lane >> 4;
+  f64x4_t acc, xac;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) r[j] = (j <= i) ? a[(K0 + i) * LDA + K0 + j] : 0.0;
+  for (int e = 0; e < 4; ++e) {
+    const int r = 4 * e + lq;
+    acc[e] = a[(K0 + max(r, lr)) * LDA + K0 + min(r, lr)];     // the LDS image holds the lower triangle
+    xac[e] = (r == lr) ? 1.0 : 0.0;
+  }
   bool bad = false;
+  double lcol[16], inv[16];
+  double pk = lane_bcast(acc[0], 0);
+  constexpr int XLAG = 3;
+  auto x_update = [&](int k) {
+    const int s = k & 3, e = k >> 2;
+    const double nw = ((lq == s) && (lr == k)) ? inv[k] - 1.0 : -lcol[k] * inv[k];   // -(v - e_k) / l_kk
+    const double xr = (lq == s) ? xac[e] : 0.0;
+    xac = __builtin_amdgcn_mfma_f64_16x16x4f64(nw, xr, xac, 0, 0, 0);
+  };
+  const int junk = lane * LDA + 64;              // pad word of a row of the 64 x 65 image: never read
+  double my_inv = 0.0;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    const double pk = lane_bcast(r[k], k);
-    if (!(pk > 0.0)) bad = true;
-    inv[k] = 1.0 / sqrt(pk > 0.0 ? pk : 1.0);
-    double acc = 0.0;
-#pragma unroll
-    for (int t = 0; t < k; ++t) acc += lane_bcast(r[t], k) * x[t];
-    const double lik = (i == k) ? sqrt(pk > 0.0 ? pk : 1.0) : r[k] * inv[k];
-    r[k] = lik;
-#pragma unroll
-    for (int j = k + 1; j < 16; ++j) r[j] -= lik * lane_bcast(lik, j);
-    x[k] = (k == i) ? inv[k] : -inv[k] * acc;
-    if (k < i) x[k] = 0.0;
-  }
-  if (bad && lane == 0) status[0] = 1;
-  if (lane < 16) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      if (j <= i) a[(K0 + i) * LDA + K0 + j] = r[j];        // L16
-      else a[(K0 + i) * LDA + K0 + j] = x[j];               // Z16[i][j] = X[j][i]
-      x16[j * 17 + i] = x[j];                               // X16[j][i]
+    const int s = k & 3, e = k >> 2;
+    const bool low = (lq == s) && (lr >= k);
+    const double am = low ? acc[e] : 0.0;                  // row k of the block where it is column k of L
+    // 1 / sqrt(pk): v_rsq_f64 (about 26 bits) + two Newton steps y <- y (1.5 - (pk / 2) y^2): ~1e-16 relative, a
+    // tenth of the instructions of 1.0 / sqrt(pk)  (a pivot <= 0 gives NaN / inf: flagged, the caller fails)
+    double iv = __builtin_amdgcn_rsq(pk);
+    {
+      const double hp = 0.5 * pk;
+      iv = iv * fma(-hp * iv, iv, 1.5);
+      iv = iv * fma(-hp * iv, iv, 1.5);
     }
-    rinv[i] = inv[i];
+    if (!(pk > 0.0)) bad = true;
+    const double v = am * iv, nv = -am * iv;               // L[lr][k]
+    if (k < 15) {
+      const int s1 = (k + 1) & 3, e1 = (k + 1) >> 2;
+      const double l10 = lane_bcast(v, 16 * s + k + 1);            // L[k+1][k]
+      const double a11 = lane_bcast(acc[e1], 16 * s1 + k + 1);     // a[k+1][k+1] before this column's update
+      pk = fma(-l10, l10, a11);
+    }
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(nv, v, acc, 0, 0, 0);
+    lcol[k] = v;
+    inv[k] = iv;
+    a[low ? (K0 + lr) * LDA + K0 + k : junk] = v;          // L16
+    my_inv = (lr == k) ? iv : my_inv;
+    if (k >= XLAG) x_update(k - XLAG);
+  }
+#pragma unroll
+  for (int k = 16 - XLAG; k < 16; ++k) x_update(k);
+  if (bad && lane == 0) status[0] = 1;
+  if (lane < 16) rinv[lane] = my_inv;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int r = 4 * e + lq;                                                         // xac[e] = X[r][lr]
+    if (r > lr) a[(K0 + lr) * LDA + K0 + r] = xac[e];                                 // Z16[lr][r] = X[r][lr]
+    x16[r * 17 + lr] = xac[e];
   }
 }
 
@@ -1317,7 +1348,7 @@ k_chol_diag_packed_f64(double* __restrict__ Aglob, int ld, double* __restrict__ 
       const int prow0 = top ? (K0 + 16 + wave * 16) : ((wave - nbelow) * 16);
       diag_tile_update_f64(a, LDA, prow0, K0 + 16, K0, !top && (wave - nbelow) == b, rb_inv, lr, lq);
     }
-    __syncthreads();
+    // (no barrier: wave 0's urgent tile is the next diagonal tile, which only wave 0 goes on to read; see the f32 kernel)
     // wave 0 factors block b + 1 while the other waves apply the rest of update b (block columns b + 2 ..)
     if (wave == 0) {
       diag_factor16_f64(a, LDA, K0 + 16, x16[(b + 1) & 1], rinv[(b + 1) & 1], lane, status);
