@@ -1126,7 +1126,7 @@ struct Filter : FilterBase {
         HIPCHK(hipEventRecord(ev_chain[gi], stream));
         HIPCHK(hipStreamWaitEvent(stream_b, ev_chain[gi], 0));
         Scope sc(this, KID_STATE_UPDATE, stream_b);
-        k_state_update<T><<<(n + 3) / 4, 256, 0, stream_b>>>(mu(), d_V, ldy, n, d_V + (size_t)npad_live * ldy, m_pad);
+        k_state_update<T><<<(n + 7) / 8, 512, 0, stream_b>>>(mu(), d_V, ldy, n, d_V + (size_t)npad_live * ldy, m_pad, d_scr + SCR_QN);   // + quaternion normalisation
         b_inflight = true;
       }
       bool split_done = false;
@@ -1187,12 +1187,11 @@ struct Filter : FilterBase {
     const T* V = d_V;
     const T* yv = d_V + (size_t)npad_live * ldy;
     if (nchunks == 1) {
-      Scope sc(this, KID_STATE_UPDATE);
-      k_state_update<T><<<(n + 3) / 4, 256, 0, stream>>>(mu(), V, ldy, n, yv, m_pad);
+      Scope sc(this, KID_STATE_UPDATE);             // mu += V y, then the quaternion normalisation (same launch)
+      k_state_update<T><<<(n + 7) / 8, 512, 0, stream>>>(mu(), V, ldy, n, yv, m_pad, d_scr + SCR_QN);
     }
     {
       Scope sc(this, KID_NORMALIZE);
-      k_normalize_quat<T><<<1, 64, 0, stream>>>(mu(), d_scr);
       k_strip_congruence<T, 4><<<(2 * n + 255) / 256, 256, 0, stream>>>(S(), ld, n, 3, d_scr + SCR_QN,
                                                                        static_cast<const T*>(nullptr));
     }

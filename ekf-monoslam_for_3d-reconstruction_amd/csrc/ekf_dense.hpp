@@ -1195,16 +1195,33 @@ __global__ void __launch_bounds__(256, 2) k_panel_direct(float* __restrict__ P, 
 // ---------------------------------------------------------------------------------------
 template <typename T>
 __global__ void k_state_update(T* __restrict__ mu, const T* __restrict__ V, int ldy, int n,
-                               const T* __restrict__ y, int m_pad) {
+                               const T* __restrict__ y, int m_pad, T* __restrict__ scr_qn = nullptr) {
+  // scr_qn != nullptr (launched with 512 lanes: rows 0..7 are workgroup 0): the workgroup that owns the quaternion
+  // rows also normalises it and leaves Qn = (|q|^2 I - q q^T) / |q|^3 (4 x 4) at scr_qn (k_normalize_quat folded in).
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (row >= n) return;
-  const T* v = V + (size_t)row * ldy;
-  T acc = T(0);
-  for (int c = lane; c < m_pad; c += 64) acc += v[c] * y[c];
+  if (row < n) {
+    const T* v = V + (size_t)row * ldy;
+    T acc = T(0);
+    for (int c = lane; c < m_pad; c += 64) acc += v[c] * y[c];
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  if (lane == 0) mu[row] += acc;
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) mu[row] += acc;
+  }
+  if (scr_qn != nullptr && blockIdx.x == 0) {
+    __threadfence_block();
+    __syncthreads();                             // rows 3..6 are written (workgroup 0 holds rows 0..7)
+    if (threadIdx.x == 0) {
+      const T q[4] = {mu[3], mu[4], mu[5], mu[6]};
+      const T nn = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+      const T norma = t_sqrt(nn);
+      const T inv3 = T(1) / (norma * norma * norma);
+      for (int i = 0; i < 4; ++i) mu[3 + i] = q[i] / norma;
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+          scr_qn[i * 4 + j] = ((i == j ? norma * norma : T(0)) - q[i] * q[j]) * inv3;
+    }
+  }
 }
 
 template <typename T>
