@@ -532,6 +532,40 @@ def test_fused_wupdate_launch_is_bit_identical(monkeypatch):
         assert np.array_equal(mu, outs[0][0]) and np.array_equal(S, outs[0][1])
 
 
+def test_profile_reports_time_and_work_of_the_downdate():
+    """EKF_OPT_PROFILE = 1 times the downdate launches with HIP events; ekf_profile_work reports their algorithmic
+    flop: n^2 x the measured columns (symmetric half) plus, for the launch that carries its chunk's W update,
+    2 (n + 1) (m - c1) x its columns -- bench.py's roofline is the ratio of the two."""
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from ekf_monoslam_amd import synthetic
+    cfg = pkg.kinect_config()
+    n_feat = 640
+    px0, z = synthetic.measurement_stream(cfg, n_feat, 3, sigma_px=0.5)
+    f = pkg.VSlamFilter(cfg, capacity_features=n_feat)
+    f.setDt(1.0 / 30.0)
+    for (u, v) in px0:
+        assert f.addFeature((u, v)) == 1
+    idx = np.arange(n_feat, dtype=np.int32)
+    f.set_option(2, 1)
+    f.profile_reset()
+    frames = 2
+    for k in range(frames):
+        f.predict()
+        f.update(z[k].reshape(-1), idx)
+    f.synchronize()
+    prof, work = f.profile(), f.profile_work()
+    ms, cnt = prof["downdate_syrk"]
+    n, m = 14 + 6 * n_feat, 2 * n_feat
+    assert cnt == 3 * frames and ms > 0                          # 10 block steps: three chunks, one downdate launch each
+    lo = frames * float(n) * n * m                               # the symmetric downdate alone
+    hi = lo + frames * 2.0 * (n + 1) * m * m                     # no W update is larger than 2 (n + 1) m^2
+    assert lo <= work["downdate_syrk"] <= hi
+    assert set(work) == {"downdate_syrk"}
+    f.profile_reset()
+    assert f.profile_work() == {} and "downdate_syrk" not in f.profile()
+
+
 def test_largest_config_n4000_properties():
     """BASELINE configs[4] size on one GPU (N = M = 4000, n = 24014, 63 block steps, 2 x 2.3 GB of Sigma):
     one predict + update + a resize; the same size-independent properties as the N = 1000 test."""
