@@ -215,7 +215,10 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
     run_steps(flt, d_z, d_idx, n_feat, 0, args.warmup, bpf)
     flt.synchronize()
     torch.cuda.synchronize()
-    flt.set_option(2, 1)                    # EKF_OPT_PROFILE: events around the dominant kernels only
+    # EKF_OPT_PROFILE: HIP events around the dominant kernel only, and only in every 8th frame of the timed region
+    # (an event pair costs ~6 us of queue time; short runs time every frame)
+    sample = 8 if args.steps >= 64 else 1
+    flt.set_option(2, 3 if sample == 8 else 1)
     flt.profile_reset()
     t0 = time.perf_counter()
     run_steps(flt, d_z, d_idx, n_feat, args.warmup, args.steps, bpf)
@@ -244,13 +247,13 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
         # n^2 x the real columns of every downdate launch (symmetric half); with the default pipeline the
         # first chunk's launch also carries that chunk's W update (2 (n+1)(m - c1) x its columns), counted with it.
         t_k = syrk_ms / syrk_cnt * 1e-3
-        pieces = max(1, round(syrk_cnt / args.steps))
+        pieces = max(1, round(syrk_cnt * sample / args.steps))
         flop = work.get("downdate_syrk", 0.0) / syrk_cnt
         ach = flop / t_k / 1e12
         roofline = {"kernel": "downdate_syrk (k_gemm_nt_mfma, f32 MFMA 32x32x2)", "bound": "mfma",
                     "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F32_MFMA_TF, 4), "traffic": None,
-                    "avg_launch_ms": round(t_k * 1e3, 4), "launches": syrk_cnt,
+                    "avg_launch_ms": round(t_k * 1e3, 4), "launches": syrk_cnt, "timed_every_nth_step": sample,
                     "algorithmic_flop_per_launch": flop, "launches_per_step": pieces,
                     "note": ("%d launches per step (column chunks of V; all but the last on 224 of 256 CUs beside the "
                              "serial Cholesky chain, EKF_OPT_PIPELINE; the first also carries its chunk's W update); "

@@ -199,6 +199,8 @@ struct Filter : FilterBase {
   struct Pending { int kid; hipEvent_t a, b; };
   std::vector<Pending> pending;
   std::vector<hipEvent_t> pool;
+  static constexpr int kProfileSamplePeriod = 8;
+  long long frame_seq = 0;                              // updates since the last profile reset (EKF_OPT_PROFILE = 3 samples on it)
   double prof_ms[KID_COUNT];
   long long prof_cnt[KID_COUNT];
   double prof_work[KID_COUNT];                          // algorithmic flop of the timed launches (downdate only)
@@ -229,9 +231,10 @@ struct Filter : FilterBase {
 
   // ---- profiling helpers ---------------------------------------------------------------
   bool prof_on(int kid) const {
-    if (opt_profile >= 2) return true;
-    if (opt_profile == 1)
-      return kid == KID_DOWNDATE || kid == KID_PROPAGATE_STREAMING;
+    if (opt_profile == 2) return true;
+    const bool dominant = (kid == KID_DOWNDATE || kid == KID_PROPAGATE_STREAMING);
+    if (opt_profile == 1) return dominant;
+    if (opt_profile == 3) return dominant && (frame_seq % kProfileSamplePeriod == 0);   // every 8th frame: an event pair costs ~6 us of queue time
     return false;
   }
   hipEvent_t get_event() {
@@ -1199,6 +1202,7 @@ struct Filter : FilterBase {
     last_m = m; last_m_pad = m_pad; last_n = n;
     have_update = true;
     have_meas = false;                                    // h/H belong to the pre-update state
+    ++frame_seq;
     return EKF_OK;
   }
 
@@ -1703,6 +1707,7 @@ struct Filter : FilterBase {
   int profile_reset() override {
     hipSetDevice(device);
     resolve_profile();
+    frame_seq = 0;
     memset(prof_ms, 0, sizeof(prof_ms));
     memset(prof_cnt, 0, sizeof(prof_cnt));
     memset(prof_work, 0, sizeof(prof_work));

@@ -70,7 +70,8 @@ enum ekf_option {
    * fp64: v_mfma_f64_16x16x4_f64); 0: plain VALU tiles. */
   EKF_OPT_USE_MFMA = 1,
   /* profiling level: 0 off, 1 HIP events around the dominant kernels (downdate, streaming propagate),
-   * 2 around every kernel (each pair of events costs a few microseconds of launch gap). */
+   * 2 around every kernel, 3 as 1 but only in every 8th update since the last ekf_profile_reset (each pair of
+   * events costs ~6 microseconds of queue time: 5 % of a step at N = 200). */
   EKF_OPT_PROFILE = 2,
   /* Chunked factorisation: 0 = one chunk, one stream (plain blocked Cholesky + one solve + one downdate);
    * 1 = the default three column chunks, the solve / W-update / downdate of every chunk but the last on a
