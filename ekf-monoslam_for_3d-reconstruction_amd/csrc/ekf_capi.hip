@@ -921,26 +921,26 @@ struct Filter : FilterBase {
     }
     const T* zp = cur_z ? cur_z : d_z;
     const int* ip = cur_midx ? cur_midx : d_midx;
-    if (with_nu) {
-      Scope sc(this, KID_INNOVATION);
-      k_innovation<T><<<(std::max(m_pad, 64) + 255) / 256, 256, 0, stream>>>(zp, d_h, ip, M, plane, mu(), nu_row, m_pad,
-                                                                          d_counters);
-      counter_next = 0;
-    }
+    if (with_nu) counter_next = 0;
     // small problems are latency-bound: fewer rows / features per workgroup so that the grid fills the chip
     const bool small = (size_t)n * m_pad < ((size_t)1 << 22);
     {
+      // W = Sigma H^T; with_nu: one more slab of workgroups forms nu = z - h and clears the work-queue heads
+      // (k_innovation folded into this launch)
       Scope sc(this, KID_SIGMA_HT);
+      const int extra = with_nu ? 1 : 0;
+      const T* zq = with_nu ? zp : nullptr;
+      T* nuq = with_nu ? nu_row : nullptr;
       if (small) {
         constexpr int RB = 4;
-        dim3 grid((m_pad / 2 + 255) / 256, (n + RB - 1) / RB);
+        dim3 grid((m_pad / 2 + 255) / 256, (n + RB - 1) / RB + extra);
         k_sigma_ht<T, RB><<<grid, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, ip, M, plane, d_W, ldy,
-                                                  m_pad, 0, n);
+                                                  m_pad, 0, n, zq, d_h, mu(), nuq, d_counters);
       } else {
         constexpr int RB = 32;
-        dim3 grid((m_pad / 2 + 255) / 256, (n + RB - 1) / RB);
+        dim3 grid((m_pad / 2 + 255) / 256, (n + RB - 1) / RB + extra);
         k_sigma_ht<T, RB><<<grid, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, ip, M, plane, d_W, ldy,
-                                                  m_pad, 0, n);
+                                                  m_pad, 0, n, zq, d_h, mu(), nuq, d_counters);
       }
     }
     {

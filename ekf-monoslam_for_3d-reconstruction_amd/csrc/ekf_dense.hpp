@@ -48,10 +48,32 @@ __global__ void k_sigma_ht(const T* __restrict__ S, int ld, int n,
                            const T* __restrict__ Hc, const T* __restrict__ Hf,
                            const int* __restrict__ pos, const int* __restrict__ coding,
                            const int* __restrict__ midx, int M, int plane,
-                           T* __restrict__ W, int ldy, int m_pad, int row_begin, int row_end) {
+                           T* __restrict__ W, int ldy, int m_pad, int row_begin, int row_end,
+                           const T* __restrict__ z = nullptr, const T* __restrict__ h = nullptr,
+                           const T* __restrict__ mu = nullptr, T* __restrict__ nu = nullptr,
+                           int* __restrict__ counters = nullptr) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;    // measurement slot
-  const int row0 = row_begin + blockIdx.y * RB;           // rows [row_begin, row_end) of Sigma
   const int nslots = m_pad / 2;
+  if (nu != nullptr && blockIdx.y == gridDim.y - 1) {
+    // one more slab of workgroups than the rows need: the innovation nu = z - h (k_innovation folded into this
+    // launch: one launch less in front of the chain) and the reset of the work-queue heads of this update
+    if (counters)
+      for (int c = k; c < kQueueCounters; c += gridDim.x * blockDim.x) counters[c] = 0;
+    if (k >= nslots) return;
+#pragma unroll
+    for (int t = 2 * k; t < 2 * k + 2; ++t) {
+      T v = T(0);
+      if (t < 2 * M) {
+        v = z[t] - h[2 * midx[t >> 1] + (t & 1)];
+      } else if (plane && t < 2 * M + 3) {
+        const int e = t - 2 * M;
+        v = -mu[e == 0 ? 1 : (e == 1 ? 4 : 6)];
+      }
+      nu[t] = v;
+    }
+    return;
+  }
+  const int row0 = row_begin + blockIdx.y * RB;           // rows [row_begin, row_end) of Sigma
   if (k >= nslots) return;
   const int row1 = min(row0 + RB, min(row_end, n));
   if (k < M) {
