@@ -202,8 +202,20 @@ __global__ void k_propagate_streaming(const T* __restrict__ src, T* __restrict__
       T* d = dst + (size_t)row * ld;
       // vector chunks [16, n): pure copy (16 is the first vector boundary past column 12)
       const int nv = (n + V - 1) / V;            // ld is padded, reading to the vector end is in-bounds
-      for (int cv = 16 / V + threadIdx.x; cv < nv; cv += blockDim.x)
-        *reinterpret_cast<vec_t*>(d + (size_t)cv * V) = *reinterpret_cast<const vec_t*>(s + (size_t)cv * V);
+      // (eight loads in flight per lane before the first store)
+      for (int cv0 = 16 / V + threadIdx.x; cv0 < nv; cv0 += 8 * blockDim.x) {
+        vec_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int cv = cv0 + u * blockDim.x;
+          if (cv < nv) v[u] = *reinterpret_cast<const vec_t*>(s + (size_t)cv * V);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int cv = cv0 + u * blockDim.x;
+          if (cv < nv) *reinterpret_cast<vec_t*>(d + (size_t)cv * V) = v[u];
+        }
+      }
       if (threadIdx.x < 16) {                   // columns 0..15: 13 transformed + 3 copied
         const int c = threadIdx.x;
         T acc;
