@@ -827,6 +827,12 @@ struct Filter : FilterBase {
         return;
       }
     }
+    if constexpr (!kIsF32) {
+      if (opt_mfma && nb == 64 && opt_panel_direct) {
+        k_panel_direct_f64<<<(vrows + 63) / 64, 256, 0, st>>>(P, ldy, Dj, vrows);
+        return;
+      }
+    }
     gemm<ROLE_PANEL, false, 64, 128>(P, ldy, Dj, nb, P, ldy, vrows, nb, nb, T(1), T(0), 0, 0, 0, 0, 0, st);
   }
 

@@ -1343,6 +1343,57 @@ __device__ __forceinline__ void diag_factor16_f64(double* a, int LDA, int K0, do
   }
 }
 
+// fp64 twin of k_panel_direct (block 64): P <- P Linv^T in place for `rows` rows, Linv the 64 x 64 lower-triangular
+// inverse k_chol_diag_packed_f64 left in Dinv (row-major, stride 64).  One wave = 16 rows x all 64 columns, its A
+// fragments (pairs of doubles: k = 8 u + 2 lq + e) in registers before its first store; Linv staged in LDS, row pitch
+// 33 x 16 bytes; v_mfma_f64_16x16x4_f64 (C layout: register e = row 4 e + lq); column tile ct needs k < 16 (ct + 1).
+__global__ void __launch_bounds__(256, 2) k_panel_direct_f64(double* __restrict__ P, int ldp, const double* __restrict__ Dinv,
+                                                            int rows) {
+  constexpr int NB = 64, PITCH = 66;
+  __shared__ double sl[NB * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  __builtin_amdgcn_s_setprio(2);                 // part of the serial chain
+  const int row0 = blockIdx.x * 64 + wave * 16;
+  const bool live = row0 < rows;
+  f64x2 fa[8];
+  double* Prow = P + (size_t)(row0 + lr) * ldp;
+  if (live) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) fa[u] = *reinterpret_cast<const f64x2*>(Prow + 8 * u + 2 * lq);
+  }
+  {
+    f64x2 v[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int q = tid + 256 * p;               // pair index: row q / 32, columns 2 (q % 32) ..
+      v[p] = *reinterpret_cast<const f64x2*>(Dinv + (size_t)(q >> 5) * NB + 2 * (q & 31));
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int q = tid + 256 * p;
+      *reinterpret_cast<f64x2*>(sl + (q >> 5) * PITCH + 2 * (q & 31)) = v[p];
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    f64x4_t acc = {0.0, 0.0, 0.0, 0.0};
+    const double* bl = sl + (16 * ct + lr) * PITCH + 2 * lq;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (u <= 2 * ct + 1) {
+        const f64x2 fb = *reinterpret_cast<const f64x2*>(bl + 8 * u);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[u][e], fb[e], acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) P[(size_t)(row0 + 4 * e + lq) * ldp + 16 * ct + lr] = acc[e];
+  }
+}
+
 __global__ void __launch_bounds__(512)
 k_chol_diag_packed_f64(double* __restrict__ Aglob, int ld, double* __restrict__ Dinv, int* __restrict__ status,
                        int nblk_real = 4) {
