@@ -163,8 +163,32 @@ def cpu_baseline(cfg_name, n_feat, px0, zs, threads):
     return float(np.median(td)), float(np.median(ts_)), used, len(td)
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks as fresh child processes through
+    torch.distributed.run, exactly as the driver does, forward rank 0's JSON line and exit with the child's
+    code.  Nothing in THIS process has touched the GPU yet (no os.exec from a process that has: the children are
+    ordinary subprocesses)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={env_world} of the launcher")
     import torch
     import torch.distributed as dist
     from __graft_entry__ import load_package

@@ -62,6 +62,7 @@ _PROTOS = {
     "ekf_remove_features": (C.c_int, [_P, _P, C.c_int]),
     "ekf_predict": (C.c_int, [_P, _P, _P, C.c_int]),
     "ekf_measure": (C.c_int, [_P]),
+    "ekf_get_motion_jacobian": (C.c_int, [_P, _P, _P]),
     "ekf_get_predictions": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "ekf_update": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
     "ekf_update_device": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
@@ -88,6 +89,7 @@ _PROTOS = {
     "ekf_set_sigma_block": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ekf_covariance_parameter": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "ekf_feature_xyz": (C.c_int, [_P, C.c_int, _P, _P]),
+    "ekf_check_invariants": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ekf_profile_kernels": (C.c_int, []),
     "ekf_profile_kernel_name": (C.c_char_p, [C.c_int]),
     "ekf_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),

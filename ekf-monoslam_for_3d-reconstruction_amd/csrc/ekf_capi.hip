@@ -64,6 +64,7 @@ struct FilterBase {
   virtual int remove_features(const int*, int) = 0;
   virtual int predict(const void*, const void*, int) = 0;
   virtual int measure() = 0;
+  virtual int motion_jacobian(void*, void*) = 0;
   virtual int get_predictions(void*, unsigned char*, unsigned char*, void*, void*, void*) = 0;
   virtual int update(const void*, const int*, int, int, bool) = 0;
   virtual int innovation_covariance(const int*, int, int, void*) = 0;
@@ -78,6 +79,7 @@ struct FilterBase {
   virtual int get_sigma(void*, int, int, int, int) = 0;
   virtual int set_sigma(const void*, int, int, int, int) = 0;
   virtual int covariance_parameter(double*) = 0;
+  virtual int check_invariants(double*, double*, double*) = 0;
   virtual int feature_xyz(int, void*, void*) = 0;
   virtual int profile_read(int, double*, long long*) = 0;
   virtual int profile_reset() = 0;
@@ -331,8 +333,8 @@ struct Filter : FilterBase {
     HIPCHK(hipMalloc(&d_Dinv, (size_t)(ldy / 64) * 128 * 128 * sizeof(T)));
     HIPCHK(hipMalloc(&d_z, (size_t)ldy * sizeof(T)));
     HIPCHK(hipMalloc(&d_midx, cn * sizeof(int)));
-    HIPCHK(hipMalloc(&d_status, 4 * sizeof(int)));
-    HIPCHK(hipMemsetAsync(d_status, 0, 4 * sizeof(int), stream));
+    HIPCHK(hipMalloc(&d_status, 8 * sizeof(int)));          // [0] pivot <= 0, [1] bad device index list; [4..7] scratch of ekf_check_invariants
+    HIPCHK(hipMemsetAsync(d_status, 0, 8 * sizeof(int), stream));
     HIPCHK(hipMalloc(&d_tmp, 64 * sizeof(T)));
     HIPCHK(hipMalloc(&d_counters, kQueueCounters * sizeof(int)));
     HIPCHK(hipMemset(d_counters, 0, kQueueCounters * sizeof(int)));
@@ -419,8 +421,11 @@ struct Filter : FilterBase {
     int st[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(st, d_status, sizeof(st), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
-    if (st[0]) {
+    if (st[0] || st[1]) {
       HIPCHK(hipMemsetAsync(d_status, 0, 4 * sizeof(int), stream));
+      if (st[1])
+        FAIL(EKF_ERR_ARG, "ekf_update_device: a device-resident index is outside [0, N) or the list is not strictly "
+                          "ascending (indices were clamped; the state is not meaningful)");
       FAIL(EKF_ERR_NUMERIC, "innovation covariance is not positive definite (Cholesky pivot <= 0)");
     }
     return EKF_OK;
@@ -721,6 +726,7 @@ struct Filter : FilterBase {
       Scope sc(this, KID_PREDICT_CAMERA);
       k_predict_camera<T><<<1, 64, 0, stream>>>(mu(), d_scr, a);
     }
+    have_motion = true;
     if (opt_streaming) {
       const int dst = 1 - cur;
       {
@@ -745,6 +751,22 @@ struct Filter : FilterBase {
   int measure() override {
     HIPCHK(hipSetDevice(device));
     return launch_measure();
+  }
+
+  bool have_motion = false;
+  int motion_jacobian(void* Ft, void* Q) override {
+    HIPCHK(hipSetDevice(device));
+    if (!have_motion) FAIL(EKF_ERR_STATE, "no motion Jacobian: call ekf_predict first");
+    T buf[2 * 169];
+    HIPCHK(hipMemcpyAsync(buf, d_scr + SCR_FT, sizeof(buf), hipMemcpyDeviceToHost, stream));   // SCR_FT, SCR_Q adjacent
+    HIPCHK(hipStreamSynchronize(stream));
+    for (int b = 0; b < 2; ++b) {
+      T* o = static_cast<T*>(b ? Q : Ft);
+      if (!o) continue;
+      for (int r = 0; r < 13; ++r)
+        for (int c = 0; c < 13; ++c) o[c * 13 + r] = buf[b * 169 + r * 13 + c];
+    }
+    return EKF_OK;
   }
 
   // 2x2 St blocks on demand (they need the propagated Sigma and the current H; nothing on the device
@@ -941,12 +963,12 @@ struct Filter : FilterBase {
         constexpr int RB = 4;
         dim3 grid((m_pad / 2 + 255) / 256, (n + RB - 1) / RB + extra);
         k_sigma_ht<T, RB><<<grid, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, ip, M, plane, d_W, ldy,
-                                                  m_pad, 0, n, zq, d_h, mu(), nuq, d_counters);
+                                                  m_pad, 0, n, N, zq, d_h, mu(), nuq, d_counters, d_status);
       } else {
         constexpr int RB = 32;
         dim3 grid((m_pad / 2 + 255) / 256, (n + RB - 1) / RB + extra);
         k_sigma_ht<T, RB><<<grid, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, ip, M, plane, d_W, ldy,
-                                                  m_pad, 0, n, zq, d_h, mu(), nuq, d_counters);
+                                                  m_pad, 0, n, N, zq, d_h, mu(), nuq, d_counters, d_status);
       }
     }
     {
@@ -957,12 +979,12 @@ struct Filter : FilterBase {
         constexpr int KB = 1;
         dim3 grid((m_pad + 255) / 256, std::max(1, (M + KB - 1) / KB) + (m_pad - 2 * M + 7) / 8);
         k_innovation_cov<T, KB><<<grid, 256, 0, stream>>>(d_W, ldy, d_Hc, d_Hf, d_pos, d_coding, ip, M, plane,
-                                                        T(sigma_pixel_2), T(0.00001), d_Y, m_pad, 0, M, zid, ct, strip_rows);
+                                                        T(sigma_pixel_2), T(0.00001), d_Y, m_pad, 0, M, zid, N, ct, strip_rows);
       } else {
         constexpr int KB = 8;
         dim3 grid((m_pad + 255) / 256, std::max(1, (M + KB - 1) / KB) + (m_pad - 2 * M + 7) / 8);
         k_innovation_cov<T, KB><<<grid, 256, 0, stream>>>(d_W, ldy, d_Hc, d_Hf, d_pos, d_coding, ip, M, plane,
-                                                        T(sigma_pixel_2), T(0.00001), d_Y, m_pad, 0, M, zid, ct, strip_rows);
+                                                        T(sigma_pixel_2), T(0.00001), d_Y, m_pad, 0, M, zid, N, ct, strip_rows);
       }
     }
     HIPCHK(hipGetLastError());
@@ -979,8 +1001,10 @@ struct Filter : FilterBase {
     if (!have_meas) FAIL(EKF_ERR_STATE, "ekf_update needs the h/H of ekf_predict or ekf_measure");
     if (M > 0 && (!z || !idx)) FAIL(EKF_ERR_ARG, "z / indices are NULL");
     if (!on_device) {
-      for (int k = 0; k < M; ++k)
+      for (int k = 0; k < M; ++k) {
         if (idx[k] < 0 || idx[k] >= N) FAIL(EKF_ERR_ARG, "feature index out of range");
+        if (k > 0 && idx[k - 1] >= idx[k]) FAIL(EKF_ERR_ARG, "measured indices must be strictly ascending");
+      }
     }
     cur_z = nullptr;
     cur_midx = nullptr;
@@ -1335,6 +1359,22 @@ struct Filter : FilterBase {
     *out = double(acc);
     return EKF_OK;
   }
+  int check_invariants(double* pad, double* asym, double* big) override {
+    HIPCHK(hipSetDevice(device));
+    unsigned int* d_out = reinterpret_cast<unsigned int*>(d_status + 4);      // 4 spare ints behind the status words
+    HIPCHK(hipMemsetAsync(d_out, 0, 4 * sizeof(int), stream));
+    dim3 grid(std::min(16, (ld + 255) / 256), n_pad);
+    k_check_invariants<T><<<grid, 256, 0, stream>>>(S(), ld, n, n_pad, d_out);
+    unsigned int h[4];
+    HIPCHK(hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    float f[3];
+    memcpy(f, h, sizeof(f));
+    if (pad) *pad = f[0];
+    if (asym) *asym = f[1];
+    if (big) *big = f[2];
+    return check_status();
+  }
   int feature_xyz(int index, void* xyz, void* cov) override {
     HIPCHK(hipSetDevice(device));
     if (index < 0 || index >= N) FAIL(EKF_ERR_ARG, "feature index out of range");
@@ -1537,17 +1577,17 @@ struct Filter : FilterBase {
     }
     { Scope sc(this, KID_INNOVATION);
       k_innovation<T><<<(std::max(m_pad, 64) + 255) / 256, 256, 0, stream>>>(d_z, d_h, d_midx, M, plane, mu(), nu_row, m_pad,
-                                                                          d_counters);
+                                                                          d_counters, N, d_status);
       counter_next = 0; }
     {
       Scope sc(this, KID_SIGMA_HT);
       constexpr int RB = 32;
       dim3 g1((m_pad / 2 + 255) / 256, (camera_dim + RB - 1) / RB);
       k_sigma_ht<T, RB><<<g1, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane, d_W, ldy,
-                                              m_pad, 0, camera_dim);
+                                              m_pad, 0, camera_dim, N);
       dim3 g2((m_pad / 2 + 255) / 256, (sh_r1 - sh_r0 + RB - 1) / RB);
       k_sigma_ht<T, RB><<<g2, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane, d_W, ldy,
-                                              m_pad, sh_r0, sh_r1);
+                                              m_pad, sh_r0, sh_r1, N);
     }
     {
       Scope sc(this, KID_INNOVATION_COV);
@@ -1555,7 +1595,7 @@ struct Filter : FilterBase {
       dim3 grid((m_pad + 255) / 256, std::max(1, (sh_f1 - sh_f0 + KB - 1) / KB) + (m_pad - 2 * M + 7) / 8);
       k_innovation_cov<T, KB><<<grid, 256, 0, stream>>>(d_W, ldy, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane,
                                                       T(sigma_pixel_2), T(0.00001), d_Y, m_pad, sh_f0, sh_f1,
-                                                      static_cast<T*>(nullptr));
+                                                      static_cast<T*>(nullptr), N);
     }
     HIPCHK(hipGetLastError());
     sh_m = m; sh_m_pad = m_pad; sh_plane = plane;
@@ -1813,6 +1853,7 @@ int ekf_remove_features(ekf_filter* f, const int* idx, int count) {
 
 int ekf_predict(ekf_filter* f, const void* t, const void* r, int vc) { IMPL_OR_ARG(f); return f->impl->predict(t, r, vc); }
 int ekf_measure(ekf_filter* f) { IMPL_OR_ARG(f); return f->impl->measure(); }
+int ekf_get_motion_jacobian(ekf_filter* f, void* Ft, void* Q) { IMPL_OR_ARG(f); return f->impl->motion_jacobian(Ft, Q); }
 int ekf_get_predictions(ekf_filter* f, void* h, unsigned char* vis, unsigned char* rem, void* s2, void* hc, void* hf) {
   IMPL_OR_ARG(f);
   return f->impl->get_predictions(h, vis, rem, s2, hc, hf);
@@ -1853,6 +1894,7 @@ int ekf_set_sigma_block(ekf_filter* f, const void* in, int r0, int c0, int rows,
   return f->impl->set_sigma(in, r0, c0, rows, cols);
 }
 int ekf_covariance_parameter(ekf_filter* f, double* out) { IMPL_OR_ARG(f); if (!out) return EKF_ERR_ARG; return f->impl->covariance_parameter(out); }
+int ekf_check_invariants(ekf_filter* f, double* pad, double* asym, double* big) { IMPL_OR_ARG(f); return f->impl->check_invariants(pad, asym, big); }
 int ekf_feature_xyz(ekf_filter* f, int index, void* xyz, void* cov) { IMPL_OR_ARG(f); return f->impl->feature_xyz(index, xyz, cov); }
 
 int ekf_profile_kernels(void) { return ekf::KID_COUNT; }

@@ -19,16 +19,27 @@ namespace ekf {
 // ---------------------------------------------------------------------------------------
 constexpr int kQueueCounters = 256;              // 8 heads (one per XCD) x up to 32 queued launches per update
 
+// A measured list read from DEVICE memory (ekf_update_device) cannot be checked on the host: an entry outside
+// [0, nfeat) or a list that is not strictly ascending raises status[1] (the next synchronising call returns
+// EKF_ERR_ARG) and every kernel clamps the index it uses, so nothing is read out of bounds meanwhile.
+__device__ __forceinline__ int clamp_feature(int fi, int nfeat) { return min(max(fi, 0), nfeat - 1); }
+__device__ __forceinline__ void check_measured_entry(const int* __restrict__ midx, int k, int nfeat,
+                                                     int* __restrict__ status) {
+  const int fi = midx[k];
+  if (status && (fi < 0 || fi >= nfeat || (k > 0 && midx[k - 1] >= fi))) status[1] = 1;
+}
+
 template <typename T>
 __global__ void k_innovation(const T* __restrict__ z, const T* __restrict__ h, const int* __restrict__ midx,
                              int M, int plane, const T* __restrict__ mu, T* __restrict__ nu, int m_pad,
-                             int* __restrict__ counters) {
+                             int* __restrict__ counters, int nfeat, int* __restrict__ status) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (counters && t < kQueueCounters) counters[t] = 0;   // work-queue heads of this update's queued GEMMs
   if (t >= m_pad) return;
   T v = T(0);
   if (t < 2 * M) {
-    v = z[t] - h[2 * midx[t >> 1] + (t & 1)];
+    if ((t & 1) == 0) check_measured_entry(midx, t >> 1, nfeat, status);
+    v = z[t] - h[2 * clamp_feature(midx[t >> 1], nfeat) + (t & 1)];
   } else if (plane && t < 2 * M + 3) {
     const int e = t - 2 * M;
     v = -mu[e == 0 ? 1 : (e == 1 ? 4 : 6)];
@@ -49,9 +60,10 @@ __global__ void k_sigma_ht(const T* __restrict__ S, int ld, int n,
                            const int* __restrict__ pos, const int* __restrict__ coding,
                            const int* __restrict__ midx, int M, int plane,
                            T* __restrict__ W, int ldy, int m_pad, int row_begin, int row_end,
+                           int nfeat,
                            const T* __restrict__ z = nullptr, const T* __restrict__ h = nullptr,
                            const T* __restrict__ mu = nullptr, T* __restrict__ nu = nullptr,
-                           int* __restrict__ counters = nullptr) {
+                           int* __restrict__ counters = nullptr, int* __restrict__ status = nullptr) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;    // measurement slot
   const int nslots = m_pad / 2;
   if (nu != nullptr && blockIdx.y == gridDim.y - 1) {
@@ -60,11 +72,12 @@ __global__ void k_sigma_ht(const T* __restrict__ S, int ld, int n,
     if (counters)
       for (int c = k; c < kQueueCounters; c += gridDim.x * blockDim.x) counters[c] = 0;
     if (k >= nslots) return;
+    if (k < M) check_measured_entry(midx, k, nfeat, status);
 #pragma unroll
     for (int t = 2 * k; t < 2 * k + 2; ++t) {
       T v = T(0);
       if (t < 2 * M) {
-        v = z[t] - h[2 * midx[t >> 1] + (t & 1)];
+        v = z[t] - h[2 * clamp_feature(midx[t >> 1], nfeat) + (t & 1)];
       } else if (plane && t < 2 * M + 3) {
         const int e = t - 2 * M;
         v = -mu[e == 0 ? 1 : (e == 1 ? 4 : 6)];
@@ -77,7 +90,7 @@ __global__ void k_sigma_ht(const T* __restrict__ S, int ld, int n,
   if (k >= nslots) return;
   const int row1 = min(row0 + RB, min(row_end, n));
   if (k < M) {
-    const int fi = midx[k];
+    const int fi = clamp_feature(midx[k], nfeat);
     const int p = pos[fi];
     const int fs = coding[fi] ? 3 : 6;
     T hc[14], hf[12];
@@ -142,7 +155,7 @@ __global__ void k_innovation_cov(const T* __restrict__ W, int ldy,
                                  const int* __restrict__ pos, const int* __restrict__ coding,
                                  const int* __restrict__ midx, int M, int plane, T r_pix, T r_plane,
                                  T* __restrict__ Sm, int m_pad, int k_begin, int k_end, T* __restrict__ Zid,
-                                 ChunkTab tab = ChunkTab{0, {}}, int strip_rows = 0) {
+                                 int nfeat, ChunkTab tab = ChunkTab{0, {}}, int strip_rows = 0) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= m_pad) return;
   const int m = 2 * M + (plane ? 3 : 0);
@@ -154,7 +167,7 @@ __global__ void k_innovation_cov(const T* __restrict__ W, int ldy,
   const int k0 = k_begin + blockIdx.y * KB;               // measured features [k_begin, k_end)
   if (blockIdx.y < nfb)
   for (int k = k0; k < min(k0 + KB, k_end); ++k) {
-    const int fi = midx[k];
+    const int fi = clamp_feature(midx[k], nfeat);
     const int p = pos[fi];
     const int fs = coding[fi] ? 3 : 6;
     const T* hc = Hc + (size_t)fi * 14;
@@ -1213,19 +1226,43 @@ __global__ void __launch_bounds__(256, 2) k_panel_direct(float* __restrict__ P, 
 }
 
 // ---------------------------------------------------------------------------------------
-// mu[i] += sum_c V[i][c] y[c]   (K nu = V (L^-1 nu)); one wave per row.
+// mu[i] += sum_c V[i][c] y[c]   (K nu = V (L^-1 nu)): a GEMV that streams V once (n x m_pad, 49 MB at N = M = 1000).
+// One wave per row, 16-byte loads, the loads of up to eight 64-lane sweeps of the row in flight before the first
+// multiply (a 2048-column row is 8 KiB = 8 loads per lane, all outstanding at once); y comes through L1 / L2 (every
+// wave reads the same 8 KiB).  m_pad is a multiple of 64, so a sweep never runs past the padded row.
 // ---------------------------------------------------------------------------------------
 template <typename T>
-__global__ void k_state_update(T* __restrict__ mu, const T* __restrict__ V, int ldy, int n,
-                               const T* __restrict__ y, int m_pad, T* __restrict__ scr_qn = nullptr) {
+__global__ void __launch_bounds__(512)
+k_state_update(T* __restrict__ mu, const T* __restrict__ V, int ldy, int n,
+               const T* __restrict__ y, int m_pad, T* __restrict__ scr_qn = nullptr) {
   // scr_qn != nullptr (launched with 512 lanes: rows 0..7 are workgroup 0): the workgroup that owns the quaternion
   // rows also normalises it and leaves Qn = (|q|^2 I - q q^T) / |q|^3 (4 x 4) at scr_qn (k_normalize_quat folded in).
+  constexpr int VEC = 16 / sizeof(T);
+  typedef T vec_t __attribute__((ext_vector_type(VEC)));
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row < n) {
     const T* v = V + (size_t)row * ldy;
     T acc = T(0);
-    for (int c = lane; c < m_pad; c += 64) acc += v[c] * y[c];
+    constexpr int U = 8, SWEEP = 64 * VEC;
+    for (int c0 = lane * VEC; c0 < m_pad; c0 += U * SWEEP) {
+      vec_t a[U], b[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * SWEEP;
+        if (c < m_pad) {
+          a[u] = *reinterpret_cast<const vec_t*>(v + c);
+          b[u] = *reinterpret_cast<const vec_t*>(y + c);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (c0 + u * SWEEP < m_pad) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc += a[u][e] * b[u][e];
+        }
+      }
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if (lane == 0) mu[row] += acc;

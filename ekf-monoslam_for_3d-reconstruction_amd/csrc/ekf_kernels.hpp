@@ -136,7 +136,7 @@ __global__ void k_strip_congruence(T* __restrict__ S, int ld, int n, int o,
       for (int r = 0; r < K; ++r) {
         T acc = T(0);
 #pragma unroll
-        for (int k = 0; k < K; ++k) acc += sJ[r * K + k] * x[k];
+        for (int k = 0; k < K; ++k) acc = t_fma(sJ[r * K + k], x[k], acc);
         y[r] = acc;
       }
 #pragma unroll
@@ -152,7 +152,7 @@ __global__ void k_strip_congruence(T* __restrict__ S, int ld, int n, int o,
       for (int c = 0; c < K; ++c) {
         T acc = T(0);
 #pragma unroll
-        for (int k = 0; k < K; ++k) acc += x[k] * sJ[c * K + k];
+        for (int k = 0; k < K; ++k) acc = t_fma(x[k], sJ[c * K + k], acc);
         y[c] = acc;
       }
 #pragma unroll
@@ -172,12 +172,16 @@ __global__ void k_strip_congruence(T* __restrict__ S, int ld, int n, int o,
       sA[i] = acc;
     }
     __syncthreads();
+    // lower triangle only, mirrored: (J C) J^T is symmetric in exact arithmetic, not in its rounding -- and the
+    // rest of the update keeps Sigma EXACTLY symmetric (the downdate mirrors its lower tiles)
     for (int i = threadIdx.x; i < K * K; i += blockDim.x) {
       const int r = i / K, c = i % K;
+      if (c > r) continue;
       T acc = T(0);
       for (int k = 0; k < K; ++k) acc += sA[r * K + k] * sJ[c * K + k];
       if (Qm) acc += Qm[i];
       S[(size_t)(o + r) * ld + o + c] = acc;
+      S[(size_t)(o + c) * ld + o + r] = acc;
     }
   }
 }
@@ -222,7 +226,7 @@ __global__ void k_propagate_streaming(const T* __restrict__ src, T* __restrict__
         if (c < K) {
           acc = T(0);
 #pragma unroll
-          for (int k = 0; k < K; ++k) acc += s[k] * sF[c * K + k];
+          for (int k = 0; k < K; ++k) acc = t_fma(s[k], sF[c * K + k], acc);
         } else {
           acc = s[c];
         }
@@ -241,7 +245,7 @@ __global__ void k_propagate_streaming(const T* __restrict__ src, T* __restrict__
       for (int r = 0; r < K; ++r) {
         T acc = T(0);
 #pragma unroll
-        for (int k = 0; k < K; ++k) acc += sF[r * K + k] * x[k];
+        for (int k = 0; k < K; ++k) acc = t_fma(sF[r * K + k], x[k], acc);
         dst[(size_t)r * ld + t] = acc;
       }
     }
@@ -258,11 +262,14 @@ __global__ void k_propagate_streaming(const T* __restrict__ src, T* __restrict__
       sA[i] = acc;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < K * K; i += blockDim.x) {
+    for (int i = threadIdx.x; i < K * K; i += blockDim.x) {       // lower triangle, mirrored (see k_strip_congruence)
       const int r = i / K, c = i % K;
+      if (c > r) continue;
       T acc = T(0);
       for (int k = 0; k < K; ++k) acc += sA[r * K + k] * sF[c * K + k];
-      dst[(size_t)r * ld + c] = acc + Qm[i];
+      acc += Qm[i];
+      dst[(size_t)r * ld + c] = acc;
+      dst[(size_t)c * ld + r] = acc;
     }
   }
 }
@@ -471,12 +478,13 @@ __global__ void k_add_prepare(T* __restrict__ mu, const T* __restrict__ S, int l
       GS[a * 7 + c] = acc;
     }
   for (int a = 0; a < 6; ++a)
-    for (int b = 0; b < 6; ++b) {
+    for (int b = 0; b <= a; ++b) {                                     // lower triangle, mirrored: exactly symmetric
       T acc = T(0);
       for (int k = 0; k < 7; ++k) acc += GS[a * 7 + k] * G[b * 7 + k];
       acc += s_pix2 * (Jx[a * 2 + 0] * Jx[b * 2 + 0] + Jx[a * 2 + 1] * Jx[b * 2 + 1]);
       if (a == 5 && b == 5) acc += sigma_rho0;                       // unsquared, vR.cpp:365
       scr[SCR_C + a * 6 + b] = acc;
+      scr[SCR_C + b * 6 + a] = acc;
     }
 }
 
@@ -496,7 +504,7 @@ __global__ void k_add_border(T* __restrict__ S, int ld, int n, const T* __restri
     for (int a = 0; a < 6; ++a) {
       T accr = T(0), accc = T(0);
 #pragma unroll
-      for (int t = 0; t < 7; ++t) { accr += sG[a * 7 + t] * col[t]; accc += row[t] * sG[a * 7 + t]; }
+      for (int t = 0; t < 7; ++t) { accr = t_fma(sG[a * 7 + t], col[t], accr); accc = t_fma(row[t], sG[a * 7 + t], accc); }
       S[(size_t)(n + a) * ld + j] = accr;
       S[(size_t)j * ld + n + a] = accc;
     }
@@ -516,20 +524,24 @@ __global__ void k_compact_transform(const T* __restrict__ src, T* __restrict__ d
                                     int n_new, const int* __restrict__ map_src,
                                     const int* __restrict__ map_conv, const T* __restrict__ Jy) {
   const int ip = blockIdx.y;
-  const int si = map_src[ip];
-  const int ci = map_conv[ip];
+  const int si0 = map_src[ip];
+  const int ci0 = map_conv[ip];
   for (int jp = blockIdx.x * blockDim.x + threadIdx.x; jp < n_new; jp += gridDim.x * blockDim.x) {
-    const int sj = map_src[jp];
-    const int cj = map_conv[jp];
+    int si = si0, ci = ci0;
+    int sj = map_src[jp];
+    int cj = map_conv[jp];
+    // 3 x 3 block of two converted entries: Jy (S Jy^T) is symmetric only up to rounding -- evaluate the upper
+    // triangle with the roles swapped (the formula of its mirror element on a symmetric source): exactly symmetric
+    if (ci >= 0 && cj >= 0 && jp > ip) { int t = si; si = sj; sj = t; t = ci; ci = cj; cj = t; }
     T acc;
     if (ci < 0 && cj < 0) {
       acc = src[(size_t)si * ld + sj];
     } else if (ci < 0) {
       acc = T(0);
-      for (int b = 0; b < 6; ++b) acc += src[(size_t)si * ld + sj + b] * Jy[cj * 6 + b];
+      for (int b = 0; b < 6; ++b) acc = t_fma(src[(size_t)si * ld + sj + b], Jy[cj * 6 + b], acc);
     } else if (cj < 0) {
       acc = T(0);
-      for (int a = 0; a < 6; ++a) acc += Jy[ci * 6 + a] * src[(size_t)(si + a) * ld + sj];
+      for (int a = 0; a < 6; ++a) acc = t_fma(Jy[ci * 6 + a], src[(size_t)(si + a) * ld + sj], acc);
     } else {
       acc = T(0);
       for (int a = 0; a < 6; ++a) {
@@ -764,6 +776,36 @@ __global__ void k_chi2_gate(const T* __restrict__ h, const T* __restrict__ Sd, c
   const T det = s00 * s11 - s01 * s10;
   const T q = (e0 * (s11 * e0 - s01 * e1) + e1 * (-s10 * e0 + s00 * e1)) / det;
   out[k] = (q <= thr) ? 1 : 0;
+}
+
+// Invariants of the device covariance (test / debug entry ekf_check_invariants): out[0] = max |S[i][j]| outside the
+// live n x n within the n_pad x ld buffer (must be 0: the tile kernels carry no edge guards), out[1] = max
+// |S[i][j] - S[j][i]| over the live block, out[2] = max |S[i][j]| over it.  Non-negative floats order like their
+// bit patterns, so the three maxima are integer atomicMax on the float bits of the (double -> float) values.
+template <typename T>
+__global__ void k_check_invariants(const T* __restrict__ S, int ld, int n, int n_pad, unsigned int* __restrict__ out) {
+  const int i = blockIdx.y;
+  float pad = 0.f, asym = 0.f, big = 0.f;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < ld; j += gridDim.x * blockDim.x) {
+    const T v = S[(size_t)i * ld + j];
+    if (i >= n || j >= n) {
+      pad = fmaxf(pad, fabsf(float(v)));
+    } else {
+      big = fmaxf(big, fabsf(float(v)));
+      if (j < i) asym = fmaxf(asym, fabsf(float(v - S[(size_t)j * ld + i])));
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    pad = fmaxf(pad, __shfl_down(pad, off, 64));
+    asym = fmaxf(asym, __shfl_down(asym, off, 64));
+    big = fmaxf(big, __shfl_down(big, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (pad > 0.f) atomicMax(out + 0, __float_as_uint(pad));
+    if (asym > 0.f) atomicMax(out + 1, __float_as_uint(asym));
+    if (big > 0.f) atomicMax(out + 2, __float_as_uint(big));
+  }
 }
 
 template <typename T>

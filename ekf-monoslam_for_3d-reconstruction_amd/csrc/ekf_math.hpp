@@ -26,6 +26,10 @@ template <typename T> __device__ __forceinline__ T t_atan2(T y, T x);
 template <> __device__ __forceinline__ float t_atan2<float>(float y, float x) { return atan2f(y, x); }
 template <> __device__ __forceinline__ double t_atan2<double>(double y, double x) { return atan2(y, x); }
 template <typename T> __device__ __forceinline__ T t_abs(T x) { return x < T(0) ? -x : x; }
+// a * b + c with ONE rounding, spelled out: fma(a, b, c) == fma(b, a, c) bit for bit, so a row strip and the column
+// strip that mirrors it come out exactly symmetric whatever the compiler would have contracted on its own
+__device__ __forceinline__ float t_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double t_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 // q = quat(angle-axis vec)                                     (vR.cpp:1388-1406)
 template <typename T>

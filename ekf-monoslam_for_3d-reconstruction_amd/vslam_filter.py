@@ -140,6 +140,13 @@ class VSlamFilter:
     def measure(self):
         self._check(self._lib.ekf_measure(self._h))
 
+    def motionJacobian(self):
+        """Ft (13,13) of System_model_jacobian (vR.cpp:1492-1507) and Q (13,13) (vR.cpp:463-475) of the last predict."""
+        Ft = np.zeros((13, 13), self.dtype)
+        Q = np.zeros((13, 13), self.dtype)
+        self._check(self._lib.ekf_get_motion_jacobian(self._h, self._ptr(Ft), self._ptr(Q)))
+        return Ft.T.copy(), Q.T.copy()
+
     def predictions(self, jacobians: bool = False):
         """h (N,2), visible (N,), remove (N,), S2x2 (N,2,2) [, Hc (N,2,7), Hf (N,2,6)]."""
         N = self.numOfFeatures()
@@ -313,6 +320,12 @@ class VSlamFilter:
         out = C.c_double()
         self._check(self._lib.ekf_covariance_parameter(self._h, C.byref(out)))
         return out.value
+
+    def checkInvariants(self):
+        """(max |Sigma| outside the live block of the padded device buffer, max |Sigma - Sigma^T|, max |Sigma|)."""
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        self._check(self._lib.ekf_check_invariants(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def featureXYZ(self, index: int):
         """inverseDepth2XyzWorld(mode 1) and Jf Sigma Jf^T (RosVSLAMRansac.cpp:177-183)."""

@@ -124,6 +124,10 @@ int ekf_remove_features(ekf_filter* f, const int* indices, int count);
  * of St = H Sigma H^T + sigma_px^2 I that `Patch::findMatch` is gated with (vR.cpp:875).
  * t_ctl / r_ctl: 3 scalars each (may be NULL = 0); vcontrol selects Vmax vs Vmax_n. */
 int ekf_predict(ekf_filter* f, const void* t_ctl, const void* r_ctl, int vcontrol);
+/* The motion Jacobian Ft (the 13x13 block System_model_jacobian fills, vR.cpp:454, 1492-1507) and the process
+ * noise Q = Ft[:,7:13] (V / dT^2) Ft[:,7:13]^T (vR.cpp:463-475) of the last ekf_predict, 13 x 13 column-major each;
+ * either pointer may be NULL. */
+int ekf_get_motion_jacobian(ekf_filter* f, void* Ft, void* Q);
 /* Re-evaluates h / H / flags / 2x2 blocks at the current state (the recomputation at
  * vR.cpp:1080-1117 before the high-innovation update). */
 int ekf_measure(ekf_filter* f);
@@ -137,7 +141,8 @@ int ekf_get_predictions(ekf_filter* f, void* h, unsigned char* visible,
 
 /* The EKF update block (vR.cpp:1245-1284; the same block at 1053-1061 and 663-676):
  * St = H Sigma H^T + R, Kt = Sigma H^T St^-1, mu += Kt (z - h), Sigma <- (I - Kt H) Sigma,
- * normalizeQuaternion (vR.cpp:1625-1642).  `indices` (ascending feature indices, M of them)
+ * normalizeQuaternion (vR.cpp:1625-1642).  `indices` (strictly ascending feature indices, M of them: the order of
+ * position_in_z, vR.cpp:589)
  * is the measured set, z holds 2 pixels per listed feature.  plane_constraint != 0 appends
  * the forsePlane pseudo-measurement (vR.cpp:1250-1263, 1272).  M = 0 and no plane: no-op.
  * A factorisation of St that meets a non-positive pivot is reported as EKF_ERR_NUMERIC by the next
@@ -145,7 +150,14 @@ int ekf_get_predictions(ekf_filter* f, void* h, unsigned char* visible,
  * ALL measured in EVERY frame for hundreds of frames (the formulation keeps no square root and the features
  * carry no process noise: N = 1000 after ~780 frames, N = 200 after ~5400); an EKF_F64 filter does not. */
 int ekf_update(ekf_filter* f, const void* z, const int* indices, int M, int plane_constraint);
-/* Same with z / indices already resident in device memory. */
+/* Same with z (2 M scalars) and indices (M ints) already resident in DEVICE memory.  Contract:
+ *  - both buffers are read IN PLACE and ASYNCHRONOUSLY by the kernels of the queued step: they must stay allocated
+ *    and unmodified until the step has run (ekf_synchronize, any getter, or an event the caller records on the
+ *    filter's stream after this call);
+ *  - the host cannot validate them.  The first kernel of the step checks every index (inside [0, N), strictly
+ *    ascending); a bad list raises a device flag that the next synchronising call reports as EKF_ERR_ARG.  Until
+ *    then every kernel clamps the indices it uses into [0, N), so nothing is read out of bounds, but the state
+ *    after such a step is meaningless. */
 int ekf_update_device(ekf_filter* f, const void* d_z, const int* d_indices, int M,
                       int plane_constraint);
 
@@ -225,6 +237,11 @@ int ekf_get_sigma_block(ekf_filter* f, void* out, int r0, int c0, int rows, int 
 int ekf_set_sigma_block(ekf_filter* f, const void* in, int r0, int c0, int rows, int cols);
 /* Covariance_Parameter (vR.cpp:841-866): trace of Sigma[0:7,0:7]. */
 int ekf_covariance_parameter(ekf_filter* f, double* out);
+/* Invariants of the device-resident covariance, evaluated on the device (no n^2 copy): max |Sigma| outside the live
+ * n x n inside the padded buffer (the tile kernels rely on exact zeros there), max |Sigma[i][j] - Sigma[j][i]| and
+ * max |Sigma[i][j]| over the live block (the reference never symmetrises, vR.cpp:1279; this implementation keeps
+ * Sigma exactly symmetric).  Any pointer may be NULL.  Test / debug entry: no counterpart in the reference. */
+int ekf_check_invariants(ekf_filter* f, double* max_abs_outside_live, double* max_asymmetry, double* max_abs_live);
 /* inverseDepth2XyzWorld mode 1 + Jf Sigma_ff Jf^T (vR.cpp:690-738,
  * RosVSLAMRansac.cpp:177-183): world point (3) and 3x3 covariance (column-major). */
 int ekf_feature_xyz(ekf_filter* f, int index, void* xyz, void* cov3x3);

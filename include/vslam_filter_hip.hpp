@@ -52,6 +52,8 @@ class VSlamFilterHip {
   void update(const std::vector<float>& z, const std::vector<int>& indices, bool forsePlane = false) {
     check(ekf_update(h_, z.data(), indices.data(), (int)indices.size(), forsePlane ? 1 : 0));
   }
+  // Ft (member `Ft`, vR.hpp:36) and the 13x13 process noise of the last predict(), column-major
+  void motionJacobian(float Ft[169], float Q[169]) { check(ekf_get_motion_jacobian(h_, Ft, Q)); }
   void measure() { check(ekf_measure(h_)); }   // recompute h/H at the current state (vR.cpp:1080-1117)
   // The image-independent pieces of the reference's two-stage update() (vR.cpp:964-1130):
   // every 1-point hypothesis on the device; returns the index (into `indices`) of the best one.
@@ -88,9 +90,10 @@ class VSlamFilterHip {
     check(ekf_get_patch(h_, index, matching ? 1 : 0, p.data()));
     return p;
   }
-  // drawPrediction's ellipse parameters (vR.cpp:1368-1382): 5 ints per feature
+  // drawPrediction's ellipse parameters (computeEllipsoidParameters, vR.cpp:1368-1382): 3 ints per feature
+  // (semi-axis of the smaller eigenvalue, of the larger one, angle in degrees) -- what ekf_get_search_ellipses writes
   std::vector<int> searchEllipses(int sigma_size) {
-    std::vector<int> e(5 * (size_t)numOfFeatures());
+    std::vector<int> e(3 * (size_t)numOfFeatures());
     check(ekf_get_search_ellipses(h_, sigma_size, e.data()));
     return e;
   }

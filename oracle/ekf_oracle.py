@@ -503,6 +503,7 @@ class DenseFilter:
         T = self.T
         Ft, Q = self._motion(t_ctl, r_ctl, vcontrol)
         self.Ft = Ft
+        self.Q = Q
         self.predict_covariance(Ft, Q)
         self.mu[0:13] = predict_state(self.mu[0:13], t_ctl, r_ctl, self.dT, T)   # vR.cpp:480
         if self.camera_dim == 14:
@@ -824,16 +825,37 @@ class StructuredFilter(DenseFilter):
         S[3:7, :] = Q @ S[3:7, :]
         S[:, 3:7] = S[:, 3:7] @ Q.T
 
-    def sigma_Ht(self, indices, plane=False):
-        """W = Sigma H^T (n x m) from compact H."""
+    # The three per-feature loops below (measure, Sigma H^T, H X) are batched over the features: same formulas,
+    # same element type, one numpy call per term instead of one Python iteration per feature (the N = 200,
+    # 1000-frame parity test would otherwise spend minutes in the interpreter).  DenseFilter keeps the
+    # line-by-line loops of the reference; tests/test_oracle_flavours.py holds the two flavours together.
+    def _compact(self, indices):
+        """Hc (M,2,7), Hf zero-padded to (M,2,6), state columns (M,6) of the listed features (padding columns of an
+        XYZ feature point at a valid index and meet a zero of Hf)."""
         T = self.T
-        m = 2*len(indices) + (3 if plane else 0)
-        W = np.empty((self.n, m), dtype=T)
-        S = self.Sigma
+        M = len(indices)
+        Hc = np.empty((M, 2, 7), dtype=T)
+        Hf = np.zeros((M, 2, 6), dtype=T)
+        cols = np.empty((M, 6), dtype=np.int64)
         for k, i in enumerate(indices):
             ft = self.features[i]
-            p = ft.position_in_state
-            W[:, 2*k:2*k+2] = S[:, 0:7] @ ft.Hc.T + S[:, p:p+ft.size] @ ft.Hf.T
+            Hc[k] = ft.Hc
+            Hf[k, :, :ft.size] = ft.Hf
+            cols[k] = ft.position_in_state + np.minimum(np.arange(6), ft.size - 1)
+        return Hc, Hf, cols
+
+    def sigma_Ht(self, indices, plane=False):
+        """W = Sigma H^T (n x m) from compact H: column pair k = Sigma[:,0:7] Hc_k^T + Sigma[:,p_k:p_k+size] Hf_k^T."""
+        T = self.T
+        M = len(indices)
+        m = 2*M + (3 if plane else 0)
+        W = np.empty((self.n, m), dtype=T)
+        S = self.Sigma
+        if M:
+            Hc, Hf, cols = self._compact(indices)
+            Wc = S[:, 0:7] @ Hc.reshape(2*M, 7).T
+            Wf = np.einsum('nkt,kat->nka', S[:, cols], Hf).reshape(self.n, 2*M)
+            W[:, :2*M] = Wc + Wf
         if plane:
             W[:, m-3] = S[:, 1]
             W[:, m-2] = S[:, 4]
@@ -841,19 +863,95 @@ class StructuredFilter(DenseFilter):
         return W
 
     def H_times(self, X, indices, plane=False):
-        """H X for X with n rows, from compact H."""
+        """H X for X with n rows, from compact H: row pair k = Hc_k X[0:7] + Hf_k X[p_k:p_k+size]."""
         T = self.T
-        m = 2*len(indices) + (3 if plane else 0)
+        M = len(indices)
+        m = 2*M + (3 if plane else 0)
         out = np.empty((m, X.shape[1]), dtype=T)
-        for k, i in enumerate(indices):
-            ft = self.features[i]
-            p = ft.position_in_state
-            out[2*k:2*k+2, :] = ft.Hc @ X[0:7, :] + ft.Hf @ X[p:p+ft.size, :]
+        if M:
+            Hc, Hf, cols = self._compact(indices)
+            oc = Hc.reshape(2*M, 7) @ X[0:7, :]
+            of = np.einsum('kat,ktc->kac', Hf, X[cols, :]).reshape(2*M, X.shape[1])
+            out[:2*M, :] = oc + of
         if plane:
             out[m-3, :] = X[1, :]
             out[m-2, :] = X[4, :]
             out[m-1, :] = X[6, :]
         return out
+
+    def measure(self):
+        """The loop of vR.cpp:508-579 for every feature at once (see DenseFilter.measure_feature for the
+        per-feature restatement with the reference's line numbers); then the position_in_z pass (:584-592)."""
+        T = self.T
+        cfg = self.cfg
+        cam = self.cam
+        N = len(self.features)
+        if N:
+            mu = self.mu
+            r = mu[0:3]
+            qc = quat_complement(mu[3:7], T)
+            Rcw = quat2rot(qc, T)
+            pos = np.array([ft.position_in_state for ft in self.features])
+            inv = np.array([ft.coding == INV for ft in self.features])
+            F = mu[pos[:, None] + np.where(inv[:, None], np.arange(6), np.minimum(np.arange(6), 2))]   # (N,6)
+            theta, phi, ro = F[:, 3], F[:, 4], F[:, 5]
+            st, ct, sp_, cp = np.sin(theta), np.cos(theta), np.sin(phi), np.cos(phi)
+            m = np.stack([st*cp, -sp_, ct*cp], axis=1).astype(T)
+            ar = F[:, 0:3] - r
+            d = np.where(inv[:, None], ro[:, None] * ar + m, ar).astype(T)
+            Jf = np.zeros((N, 3, 6), dtype=T)                    # d(d)/d(feature): inverse2XYZ4_projecting's J / I3
+            eye = np.eye(3, dtype=T)
+            Jf[:, :, 0:3] = np.where(inv[:, None, None], ro[:, None, None] * eye, eye)
+            z0 = np.zeros(N, dtype=T)
+            Jf[:, :, 3] = np.where(inv[:, None], np.stack([ct*cp, z0, -st*cp], axis=1), 0)
+            Jf[:, :, 4] = np.where(inv[:, None], np.stack([-st*sp_, -cp, -ct*sp_], axis=1), 0)
+            Jf[:, :, 5] = np.where(inv[:, None], ar, 0)
+            scale_r = np.where(inv, -ro, T(-1)).astype(T)
+            rem = inv & (ro <= 0)
+            hC = (d @ Rcw.T).astype(T)
+            x, y, z = hC[:, 0], hC[:, 1], hC[:, 2]
+            x1, y1 = x / z, y / z
+            r2 = x1*x1 + y1*y1
+            L = T(1) + cam.k1*r2 + cam.k2*r2*r2 + cam.k3*r2*r2*r2
+            x2 = x1*L + T(2)*cam.p1*x1*y1 + cam.p2*(r2 + T(2)*x1*x1)
+            y2 = y1*L + T(2)*cam.p2*x1*y1 + cam.p1*(r2 + T(2)*y1*y1)
+            h = np.stack([cam.fx*x2 + cam.u0, cam.fy*y2 + cam.v0], axis=1).astype(T)
+            fpoly = cam.k1 + T(2)*cam.k2*r2 + T(3)*cam.k3*r2*r2
+            D = np.empty((N, 2, 2), dtype=T)                     # diff_distort_undistort, cam.cpp:18-47
+            D[:, 0, 0] = L + T(2)*fpoly*x1*x1 + T(2)*cam.p1*y1 + T(2)*cam.p2*x1 + T(4)*cam.p2*x1
+            D[:, 0, 1] = T(2)*fpoly*x1*y1 + T(2)*cam.p1*x1 + T(2)*cam.p2*y1
+            D[:, 1, 0] = T(2)*fpoly*y1*x1 + T(2)*cam.p2*y1 + T(2)*cam.p1*x1
+            D[:, 1, 1] = L + T(2)*fpoly*y1*y1 + T(2)*cam.p2*x1 + T(2)*cam.p1*y1 + T(4)*cam.p1*y1
+            Jn = np.zeros((N, 2, 3), dtype=T)
+            Jn[:, 0, 0] = T(1)/z
+            Jn[:, 0, 2] = -x/z/z
+            Jn[:, 1, 1] = T(1)/z
+            Jn[:, 1, 2] = -y/z/z
+            Jp = np.array([cam.fx, cam.fy], dtype=T)[None, :, None] * (D @ Jn)       # J_h_hC, (N,2,3)
+            half = int(cfg.window_size) // 2
+            inside = (h[:, 0] > half) & (h[:, 1] > half) & (h[:, 0] < cfg.image_width - half) & \
+                     (h[:, 1] < cfg.image_height - half)
+            vis = (~rem) & inside & (z >= 0)
+            dR = np.stack([diff_quat2rot(qc, j, T) for j in range(4)])               # (4,3,3)
+            J_hC_q = np.einsum('jab,nb->naj', dR, d) * np.array([1, -1, -1, -1], dtype=T)   # (N,3,4) incl. d_qbar_q
+            JR = Jp @ Rcw                                                            # (N,2,3)
+            Hc = np.empty((N, 2, 7), dtype=T)
+            Hc[:, :, 0:3] = scale_r[:, None, None] * JR
+            Hc[:, :, 3:7] = Jp @ J_hC_q
+            Hf = JR @ Jf                                                             # (N,2,6)
+            for i, ft in enumerate(self.features):
+                if rem[i]:
+                    ft.remove_flag = True
+                ft.is_in_innovation = bool(vis[i])
+                ft.h, ft.Hc, ft.Hf = h[i].copy(), Hc[i].copy(), Hf[i, :, :ft.size].copy()
+        j = 0
+        for ft in self.features:                                        # vR.cpp:584-592
+            if ft.is_in_innovation:
+                ft.position_in_z = 2 * j
+                j += 1
+        vis_idx = self.visible_indices()
+        self.h_out = (np.concatenate([self.features[i].h for i in vis_idx]) if vis_idx
+                      else np.zeros(0, dtype=self.T))
 
     def innovation_covariance(self, indices, plane=False):
         T = self.T

@@ -8,7 +8,7 @@ import pytest
 import ekf_oracle as o
 import image_oracle as io_
 from __graft_entry__ import load_package
-from helpers import relf
+from helpers import bound, relf
 
 pytestmark = pytest.mark.gpu
 
@@ -133,7 +133,7 @@ def test_matched_measurements_drive_the_update():
     zz = z[idx].reshape(-1)
     ref.update(zz.astype(ref.T), idx)
     g.update(zz, idx)
-    assert relf(g.getFullState(), ref.mu) < 2e-5 and relf(g.getFullSigma(), ref.Sigma) < 5e-4
+    assert bound("g.getFullState(), ref.mu", relf(g.getFullState(), ref.mu), 2e-5) and bound("g.getFullSigma(), ref.Sigma", relf(g.getFullSigma(), ref.Sigma), 5e-4)
 
 
 def test_image_error_paths():

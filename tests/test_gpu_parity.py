@@ -1,16 +1,20 @@
 """Parity of the HIP path (through the C ABI) with the CPU oracle on identical inputs.
-Tolerances are rel-Frobenius, calibrated against the oracle's own fp32-vs-fp64 gap
-(tests/test_oracle_flavours.py): fp64 HIP vs fp64 oracle <= 1e-10 on Sigma, fp32 <= 2e-4."""
+
+Errors are rel-Frobenius.  Every comparison goes through helpers.bound(): the number written here is a CEILING per
+class of comparison (fp32, one predict + update: Sigma 2e-5, mu 5e-6, Jacobians 4e-6, pixels 5e-4; fp64: 1e-10 /
+1e-12), and tests/golden/parity_bounds.json tightens each call site to 10x the error MEASURED there on the MI355X
+(profiles/r2_parity_measured.jsonl: e.g. 5e-7 .. 2e-6 on Sigma after one fp32 update, 1e-16 .. 2e-15 in fp64).
+A failing assert prints the measured value."""
 import numpy as np
 import pytest
 
 import ekf_oracle as o
-from helpers import gpu_state, make_pair, oracle_cfg, relf
+from helpers import bound, gpu_state, make_pair, oracle_cfg, relf
 
 pytestmark = pytest.mark.gpu
 
 TOL = {np.float64: dict(mu=1e-12, S=1e-10, h=1e-10, H=1e-10),
-       np.float32: dict(mu=2e-5, S=2e-4, h=2e-3, H=2e-4)}
+       np.float32: dict(mu=5e-6, S=2e-5, h=5e-4, H=4e-6)}
 
 
 def step(ref, g, seed=1235, plane=False):
@@ -31,8 +35,8 @@ def test_add_feature_matches_oracle(dtype):
     pos, cod = g.featureLayout()
     assert list(pos) == [ft.position_in_state for ft in ref.features] and not cod.any()
     t = TOL[dtype]
-    assert relf(mu, ref.mu) < t["mu"] * 10
-    assert relf(S, ref.Sigma) < t["S"]
+    assert bound("mu, ref.mu", relf(mu, ref.mu), t["mu"] * 10)
+    assert bound("S, ref.Sigma", relf(S, ref.Sigma), t["S"])
     assert g.addFeature((3.0, 100.0)) == 0            # outside the margin, vR.cpp:314
 
 
@@ -45,22 +49,24 @@ def test_predict_matches_oracle(dtype, streaming):
     g.predict([0.01, 0.0, -0.02], [0.0, 0.01, 0.0], True)
     mu, S = gpu_state(g)
     t = TOL[dtype]
-    assert relf(mu, ref.mu) < t["mu"]
-    assert relf(S, ref.Sigma) < t["S"]
+    assert bound("mu, ref.mu", relf(mu, ref.mu), t["mu"])
+    assert bound("S, ref.Sigma", relf(S, ref.Sigma), t["S"])
     h, vis, rem, S2, Hc, Hf = g.predictions(jacobians=True)
     assert list(np.nonzero(vis)[0]) == ref.visible_indices()
     assert not rem.any()
+    Ft, Q = g.motionJacobian()                          # a2: System_model_jacobian + Q, compared directly
+    assert bound("Ft, ref.Ft", relf(Ft, ref.Ft), t["H"]) and bound("Q, ref.Q", relf(Q, ref.Q), t["H"])
     for i, ft in enumerate(ref.features):
-        assert np.allclose(h[i], ft.h, atol=t["h"])
-        assert relf(Hc[i], ft.Hc) < t["H"]
-        assert relf(Hf[i], ft.Hf) < t["H"]
+        assert bound("|h - ft.h| [px]", np.abs(h[i] - ft.h).max(), t["h"])
+        assert bound("Hc[i], ft.Hc", relf(Hc[i], ft.Hc), t["H"])
+        assert bound("Hf[i], ft.Hf", relf(Hf[i], ft.Hf), t["H"])
         k = ft.position_in_z
-        assert relf(S2[i], ref.St[k:k + 2, k:k + 2]) < t["S"] * 5
+        assert bound("S2[i], ref.St[k:k + 2, k:k + 2]", relf(S2[i], ref.St[k:k + 2, k:k + 2]), t["S"] * 5)
     # second predict exercises the buffer flip of the streaming mode
     ref.predict()
     g.predict()
     mu, S = gpu_state(g)
-    assert relf(S, ref.Sigma) < t["S"]
+    assert bound("S, ref.Sigma #2", relf(S, ref.Sigma), t["S"])
 
 
 @pytest.mark.parametrize("dtype,mfma", [(np.float64, False), (np.float64, True), (np.float32, False), (np.float32, True)])
@@ -71,11 +77,11 @@ def test_update_matches_oracle(dtype, mfma, n_feat):
     g.synchronize()
     mu, S = gpu_state(g)
     t = TOL[dtype]
-    assert relf(mu, ref.mu) < t["mu"] * 5
-    assert relf(S, ref.Sigma) < t["S"]
+    assert bound("mu, ref.mu", relf(mu, ref.mu), t["mu"] * 5)
+    assert bound("S, ref.Sigma", relf(S, ref.Sigma), t["S"])
     K = g.getGain()
     assert K.shape == ref.Kt.shape
-    assert relf(K, ref.Kt) < t["S"] * 20
+    assert bound("K, ref.Kt", relf(K, ref.Kt), t["S"] * 20)
     assert abs(np.linalg.norm(mu[3:7]) - 1.0) < 1e-6
 
 
@@ -86,10 +92,10 @@ def test_innovation_covariance_matches_oracle(dtype):
     g.predict()
     vis = ref.visible_indices()
     St = g.innovationCovariance(vis)
-    assert relf(St, ref.St) < TOL[dtype]["S"]
+    assert bound("St, ref.St", relf(St, ref.St), TOL[dtype]["S"])
     sub = vis[3:11]
-    assert relf(g.innovationCovariance(sub), ref.innovation_covariance(sub)) < TOL[dtype]["S"]
-    assert relf(g.innovationCovariance(sub, True), ref.innovation_covariance(sub, True)) < TOL[dtype]["S"]
+    assert bound("g.innovationCovariance(sub), ref.innovation_covariance(sub)", relf(g.innovationCovariance(sub), ref.innovation_covariance(sub)), TOL[dtype]["S"])
+    assert bound("g.innovationCovariance(sub, True), ref.innovation_covariance(sub, True)", relf(g.innovationCovariance(sub, True), ref.innovation_covariance(sub, True)), TOL[dtype]["S"])
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -99,8 +105,8 @@ def test_dense_reference_formulation_agrees(dtype):
     step(ref, g)
     step(ref, g, seed=1236)
     mu, S = gpu_state(g)
-    assert relf(mu, ref.mu) < TOL[dtype]["mu"] * 10
-    assert relf(S, ref.Sigma) < TOL[dtype]["S"] * 2
+    assert bound("mu, ref.mu", relf(mu, ref.mu), TOL[dtype]["mu"] * 10)
+    assert bound("S, ref.Sigma", relf(S, ref.Sigma), TOL[dtype]["S"] * 2)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -113,8 +119,8 @@ def test_subset_and_plane_update(dtype):
     ref.update(z, vis, plane=True)
     g.update(z, vis, plane_constraint=True)
     mu, S = gpu_state(g)
-    assert relf(mu, ref.mu) < TOL[dtype]["mu"] * 5
-    assert relf(S, ref.Sigma) < TOL[dtype]["S"]
+    assert bound("mu, ref.mu", relf(mu, ref.mu), TOL[dtype]["mu"] * 5)
+    assert bound("S, ref.Sigma", relf(S, ref.Sigma), TOL[dtype]["S"])
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -134,26 +140,61 @@ def test_remove_and_convert(dtype):
     assert list(cod) == [ft.coding for ft in ref.features]
     mu, S = gpu_state(g)
     t = TOL[dtype]
-    assert relf(mu, ref.mu) < t["mu"] * 5 and relf(S, ref.Sigma) < t["S"]
+    assert bound("mu, ref.mu", relf(mu, ref.mu), t["mu"] * 5) and bound("S, ref.Sigma", relf(S, ref.Sigma), t["S"])
     for i in (9, 4, 0):                              # descending, like vR.cpp:1296-1299
         ref.remove_feature(i)
     g.removeFeatures([0, 4, 9])
     assert g.numOfFeatures() == 9 and g.stateDim() == ref.n
     mu, S = gpu_state(g)
-    assert relf(mu, ref.mu) < t["mu"] * 5 and relf(S, ref.Sigma) < t["S"]
+    assert bound("mu, ref.mu #2", relf(mu, ref.mu), t["mu"] * 5) and bound("S, ref.Sigma #2", relf(S, ref.Sigma), t["S"])
     xyz, cov = g.featureXYZ(1)                        # an XYZ feature after the shifts
     y_ref, c_ref = ref.feature_xyz(1)
-    assert relf(xyz, y_ref) < t["mu"] * 10 and relf(cov, c_ref) < t["S"] * 10
+    assert bound("xyz, y_ref", relf(xyz, y_ref), t["mu"] * 10) and bound("cov, c_ref", relf(cov, c_ref), t["S"] * 10)
     xyz, cov = g.featureXYZ(0)                        # inverse-depth feature: Jf Sigma Jf^T
     y_ref, c_ref = ref.feature_xyz(0)
-    assert relf(xyz, y_ref) < t["mu"] * 100 and relf(cov, c_ref) < t["S"] * 100
+    assert bound("xyz, y_ref #2", relf(xyz, y_ref), t["mu"] * 100) and bound("cov, c_ref #2", relf(cov, c_ref), t["S"] * 100)
     # mixed XYZ / inverse-depth map keeps working, and a new feature lands at the end
     assert g.addFeature((100.0, 90.0)) == 1 and ref.add_feature(100.0, 90.0) == 1
     g.setFullState(ref.mu)
     g.setSigmaBlock(ref.Sigma)
     step(ref, g, seed=99)
     mu, S = gpu_state(g)
-    assert relf(mu, ref.mu) < t["mu"] * 10 and relf(S, ref.Sigma) < t["S"] * 2
+    pad, asym, big = g.checkInvariants()                # (the injected fp32 oracle Sigma is itself asymmetric at 1e-7)
+    assert pad == 0.0 and asym <= 2e-6 * big, (pad, asym, big)
+    assert bound("mu, ref.mu #3", relf(mu, ref.mu), t["mu"] * 10) and bound("S, ref.Sigma #3", relf(S, ref.Sigma), t["S"] * 2)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_xyz_feature_jacobians_match_oracle(dtype):       # a5 (vR.cpp:552-578), compared directly
+    ref, g = make_pair(12, dtype)
+    step(ref, g)
+    for i in (1, 5, 10):
+        p = ref.features[i].position_in_state
+        ref.Sigma[p + 5, p + 5] = 1e-9
+    g.setFullState(ref.mu)
+    g.setSigmaBlock(ref.Sigma)
+    assert ref.convert2xyz_if_linear_all() == 3 and g.convert2XYZ_ifLinearAll() == 3
+    g.setFullState(ref.mu)
+    g.setSigmaBlock(ref.Sigma)
+    ref.predict()
+    g.predict()
+    h, vis, rem, S2, Hc, Hf = g.predictions(jacobians=True)
+    t = TOL[dtype]
+    seen = 0
+    for i, ft in enumerate(ref.features):
+        assert bound("|h - ft.h| [px]", np.abs(h[i] - ft.h).max(), t["h"])
+        assert bound("Hc[i], ft.Hc", relf(Hc[i], ft.Hc), t["H"])
+        if ft.coding == o.XYZ:
+            seen += 1
+            assert ft.Hf.shape == (2, 3) and not Hf[i][:, 3:].any()          # 2x3 block, padding columns zero
+            assert bound("Hf[i][:, :3], ft.Hf (XYZ)", relf(Hf[i][:, :3], ft.Hf), t["H"])
+        else:
+            assert bound("Hf[i], ft.Hf", relf(Hf[i], ft.Hf), t["H"])
+        k = ft.position_in_z
+        if ft.is_in_innovation:
+            assert bound("S2[i], St block", relf(S2[i], ref.St[k:k + 2, k:k + 2]), t["S"] * 5)
+    assert seen == 3
+    assert list(np.nonzero(vis)[0]) == ref.visible_indices()
 
 
 def test_getters_match_reference_semantics():
@@ -163,7 +204,7 @@ def test_getters_match_reference_semantics():
     assert np.isclose(g.Covariance_Parameter(), float(ref.covariance_parameter()), rtol=1e-3)
     assert g.numOfFeatures() == 8 and np.isclose(g.getDt(), 1.0 / 30.0)
     blk = g.getSigmaBlock(14, 0, 6, 7)
-    assert relf(blk, ref.Sigma[14:20, 0:7]) < 1e-3
+    assert bound("blk, ref.Sigma[14:20, 0:7]", relf(blk, ref.Sigma[14:20, 0:7]), 1e-3)
 
 
 def test_camera_dim_13():
@@ -171,7 +212,7 @@ def test_camera_dim_13():
     step(ref, g)
     mu, S = gpu_state(g)
     assert g.stateDim() == 13 + 60
-    assert relf(S, ref.Sigma) < 1e-10
+    assert bound("S, ref.Sigma", relf(S, ref.Sigma), 1e-10)
 
 
 def test_n200_stream_tracks_oracle():
@@ -191,10 +232,96 @@ def test_n200_stream_tracks_oracle():
         g.update(z, vis)
         ref64.update(z.astype(np.float64), vis)
         mu, S = gpu_state(g)
-        assert relf(mu, ref.mu) < 2e-5, k
-        assert relf(S, ref.Sigma) < 3e-4, k
-    assert relf(mu, ref64.mu) < 2e-5 and relf(S, ref64.Sigma) < 3e-4
-    assert relf(S, ref64.Sigma) <= 2.0 * relf(ref.Sigma, ref64.Sigma)
+        assert bound("mu, ref.mu", relf(mu, ref.mu), 2e-5), k
+        assert bound("S, ref.Sigma", relf(S, ref.Sigma), 3e-4), k
+    assert bound("mu, ref64.mu", relf(mu, ref64.mu), 2e-5) and bound("S, ref64.Sigma", relf(S, ref64.Sigma), 3e-4)
+    assert bound("S, ref64.Sigma #2", relf(S, ref64.Sigma), 2.0 * relf(ref.Sigma, ref64.Sigma))
+
+
+def test_n200_full_1000_frame_stream_with_resync():
+    """BASELINE configs[1] as specified: N = 200 inverse-depth features, fp32, the 1000-frame synthetic measurement
+    stream of the bench (static cloud, periodic camera trajectory, every visible feature measured in every frame).
+
+    Per frame the HIP state is compared with the fp32 structured oracle running beside it; every K = 25 frames the
+    ORACLE is re-synchronised to the HIP state (mu and the exactly symmetric Sigma are injected into it, never the other
+    way round), so each comparison measures at most K frames of independent rounding (1000-frame streams
+    diverge chaotically in fp32).  In every fifth segment (200 frames in all, the start-up segment included) an fp64
+    oracle runs from the same start as well: it is the truth of that segment.  Measured on the MI355X
+    (tools/stream_parity_probe.py, profiles/r2_stream_parity_probe.txt):
+      * HIP vs fp64 oracle: 5e-6 .. 5e-5 on Sigma, 2e-7 .. 8e-7 on mu -- held to 10x that;
+      * HIP vs fp32 oracle: 1e-4 .. 5e-4 on Sigma -- which is the fp32 ORACLE's rounding (explicit inverse and the
+        (I - K H) Sigma form, vR.cpp:1276-1279), not the HIP path's: the fp32 oracle is as far from the fp64 one.  The test
+        asserts exactly that where the fp64 truth runs: |HIP - o32| <= 1.5 |o32 - o64| + the HIP bound.
+    A free-running fp64 oracle over the whole stream (own process, beside the loop) bounds the END state."""
+    import multiprocessing as mp
+    from threadpoolctl import threadpool_limits
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from ekf_monoslam_amd import synthetic
+    import oracle_worker
+    N, frames, K = 200, 1000, 25
+    cfg = pkg.kinect_config()
+    dT = 1.0 / 30.0
+    px0, zs = synthetic.measurement_stream(cfg, N, frames, sigma_px=0.5)
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    worker = ctx.Process(target=oracle_worker.free_running_oracle, args=(px0, zs, "float64", dT, queue), daemon=True)
+    worker.start()
+    refs = {}
+    for T in (np.float32, np.float64):
+        r = o.StructuredFilter(o.Config.kinect(), T)
+        r.dT = dT
+        for (u, v) in px0:
+            assert r.add_feature(u, v) == 1
+        refs[T] = r
+    ref, ref64 = refs[np.float32], refs[np.float64]
+    g = pkg.VSlamFilter(cfg, capacity_features=N, dtype=np.float32)
+    g.setDt(dT)
+    for (u, v) in px0:
+        assert g.addFeature((u, v)) == 1
+    w = dict(mu64=0.0, S64=0.0, mu32=0.0, S32=0.0, h=0.0, excess=-1.0)
+    # n = 1214 matrices: more BLAS threads than cores only slow the oracles down (the GPU box shows 64+ hardware
+    # threads to numpy and grants 16 cores; the free-running oracle in the other process takes 4 of them)
+    limiter = threadpool_limits(limits=8)
+    truth = True                                            # is the fp64 oracle running in this segment?
+    for k in range(frames):
+        live = [ref, ref64] if truth else [ref]
+        for r in live:
+            oracle_worker.predict_no_St(r)
+        g.predict()
+        vis = ref.visible_indices()
+        h, gvis, grem, _ = g.predictions()
+        assert list(np.nonzero(gvis)[0]) == vis, k
+        w["h"] = max(w["h"], float(np.abs(h - np.stack([ft.h for ft in ref.features])).max()))
+        z = zs[k][vis].reshape(-1)
+        for r in live:
+            r.update(z.astype(r.T), vis)
+        g.update(z, vis)
+        mu, S = gpu_state(g)                               # synchronises: raises if a Cholesky pivot was not positive
+        e_mu32, e_S32 = relf(mu, ref.mu), relf(S, ref.Sigma)
+        assert e_mu32 < 1e-4 and e_S32 < 1e-2, (k, e_mu32, e_S32)   # hard stop per frame; the bounds are on the maxima
+        w["mu32"], w["S32"] = max(w["mu32"], e_mu32), max(w["S32"], e_S32)
+        if truth:
+            e_mu64, e_S64 = relf(mu, ref64.mu), relf(S, ref64.Sigma)
+            w["mu64"], w["S64"] = max(w["mu64"], e_mu64), max(w["S64"], e_S64)
+            w["excess"] = max(w["excess"], e_S32 - 1.5 * relf(ref.Sigma, ref64.Sigma))
+        if (k + 1) % K == 0:
+            truth = ((k + 1) // K) % 5 == 0
+            for r in ([ref, ref64] if truth else [ref]):
+                r.mu, r.Sigma = mu.astype(r.T), S.astype(r.T)
+    limiter.restore_original_limits()
+    assert np.array_equal(S, S.T)                             # every kernel mirrors what it computes: exactly symmetric
+    assert bound("per-frame mu vs fp64 oracle (every 5th segment), re-sync every 25", w["mu64"], 1e-5)
+    assert bound("per-frame Sigma vs fp64 oracle (every 5th segment), re-sync every 25", w["S64"], 5e-4)
+    assert bound("per-frame h [px] vs fp32 oracle", w["h"], 1e-3)
+    assert bound("per-frame mu vs fp32 oracle, re-sync every 25", w["mu32"], 1e-5)
+    assert bound("per-frame Sigma vs fp32 oracle, re-sync every 25 (the fp32 oracle's own rounding)", w["S32"], 3e-3)
+    assert w["excess"] < 5e-4, w                             # |HIP - o32| - 1.5 |o32 - o64| on Sigma: explained by the oracle
+    mu_end, S_end, partial = queue.get(timeout=300)
+    worker.join(timeout=60)
+    assert partial == 0
+    assert bound("end mu vs free-running fp64 oracle (1000 frames)", relf(mu, mu_end), 1e-4)
+    assert bound("end Sigma vs free-running fp64 oracle (1000 frames)", relf(S, S_end), 5e-3)
 
 
 def test_error_paths():
@@ -224,7 +351,7 @@ def test_nonpositive_rho_is_flagged_not_visible():     # vR.cpp:517-522
     h, vis, rem, S2, Hc, Hf = g.predictions(jacobians=True)
     assert rem[2] and not vis[2] and rem.sum() == 1
     assert ref.features[2].remove_flag and not ref.features[2].is_in_innovation
-    assert relf(Hf[2], ref.features[2].Hf) < 1e-3 and np.allclose(h[2], ref.features[2].h, atol=1e-2)
+    assert bound("Hf[2], ref.features[2].Hf", relf(Hf[2], ref.features[2].Hf), 1e-3) and np.allclose(h[2], ref.features[2].h, atol=1e-2)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -263,7 +390,7 @@ def test_ransac_hypotheses_match_oracle(dtype):        # vR.cpp:986-1034 (SURVEY
     ref.update(zz, sel)
     g.update(zz, sel)
     mu, S = gpu_state(g)
-    assert relf(S, ref.Sigma) < TOL[dtype]["S"]
+    assert bound("S, ref.Sigma", relf(S, ref.Sigma), TOL[dtype]["S"])
 
 
 def test_plane_only_update_and_empty_map():
@@ -274,7 +401,7 @@ def test_plane_only_update_and_empty_map():
     ref.update(np.zeros(0), [], plane=True)
     g.update(np.zeros(0), [], plane_constraint=True)
     mu, S = gpu_state(g)
-    assert relf(mu, ref.mu) < 1e-11 and relf(S, ref.Sigma) < 1e-9
+    assert bound("mu, ref.mu", relf(mu, ref.mu), 1e-11) and bound("S, ref.Sigma", relf(S, ref.Sigma), 1e-9)
     # remove everything, keep filtering on the 14-state camera
     g.removeFeatures(list(range(6)))
     for i in range(5, -1, -1):
@@ -286,7 +413,7 @@ def test_plane_only_update_and_empty_map():
     ref.update(np.zeros(0), [], plane=True)
     g.update(np.zeros(0), [], plane_constraint=True)
     mu, S = gpu_state(g)
-    assert relf(mu, ref.mu) < 1e-11 and relf(S, ref.Sigma) < 1e-9
+    assert bound("mu, ref.mu #2", relf(mu, ref.mu), 1e-11) and bound("S, ref.Sigma #2", relf(S, ref.Sigma), 1e-9)
     assert g.addFeature((120.0, 100.0)) == 1 and g.stateDim() == 20
 
 
@@ -298,7 +425,7 @@ def test_single_feature_update_f32():
     ref.update(z, [17])
     g.update(z, [17])
     mu, S = gpu_state(g)
-    assert relf(mu, ref.mu) < 1e-5 and relf(S, ref.Sigma) < 2e-4
+    assert bound("mu, ref.mu", relf(mu, ref.mu), 1e-5) and bound("S, ref.Sigma", relf(S, ref.Sigma), 2e-4)
 
 
 def test_map_export_table():                         # RosVSLAMRansac.cpp:340-418
@@ -365,9 +492,12 @@ def test_full_size_properties_n1000():
         assert np.all(d > 0)
         assert np.all(d[14:614] <= d_pred * (1 + 1e-5))       # a measurement never adds variance
         for mu2, S2_ in outs[1:]:
-            assert relf(mu2, mu) < 1e-5 and relf(S2_, S) < 1e-4
+            assert bound("mu2, mu", relf(mu2, mu), 1e-5) and bound("S2_, S", relf(S2_, S), 1e-4)
+    for f in filters:                                 # device-side invariants of the whole 6016 x 6016 buffer
+        pad, asym, big = f.checkInvariants()
+        assert pad == 0.0 and asym == 0.0 and big > 0.0, (pad, asym, big)
     full = filters[0].getFullSigma()
-    assert full.shape == (6014, 6014) and np.abs(full - full.T).max() <= 1e-6 * np.abs(full).max()
+    assert full.shape == (6014, 6014) and np.array_equal(full, full.T)
     w = np.linalg.eigvalsh(full[:200, :200].astype(np.float64))
     assert w.min() > -1e-6 * w.max()                  # leading block stays positive semi-definite
 
@@ -405,7 +535,7 @@ def test_two_stage_update_with_rescue(dtype):          # vR.cpp:964-1130, 1245-1
     g.update(zz, sel)
     mu, S = gpu_state(g)
     t = TOL[dtype]
-    assert relf(mu, ref.mu) < t["mu"] * 10 and relf(S, ref.Sigma) < t["S"] * 2
+    assert bound("mu, ref.mu", relf(mu, ref.mu), t["mu"] * 10) and bound("S, ref.Sigma", relf(S, ref.Sigma), t["S"] * 2)
 
 
 @pytest.mark.parametrize("dtype,mfma,chunks", [(np.float64, False, 3), (np.float64, True, 3), (np.float32, True, 3), (np.float32, True, 2),
@@ -420,21 +550,21 @@ def test_chunked_pipeline_matches_oracle(dtype, mfma, chunks):
     g.synchronize()
     mu, S = gpu_state(g)
     t = TOL[dtype]
-    assert relf(mu, ref.mu) < t["mu"] * 5
-    assert relf(S, ref.Sigma) < t["S"] * 2
+    assert bound("mu, ref.mu", relf(mu, ref.mu), t["mu"] * 5)
+    assert bound("S, ref.Sigma", relf(S, ref.Sigma), t["S"] * 2)
     assert np.abs(S - S.T).max() <= 1e-6 * np.abs(S).max()
     K = g.getGain()
-    assert K.shape == ref.Kt.shape and relf(K, ref.Kt) < t["S"] * 50
+    assert K.shape == ref.Kt.shape and bound("K, ref.Kt", relf(K, ref.Kt), t["S"] * 50)
     # a second frame on the updated state, and agreement with the one-chunk path on the same inputs
     g1 = make_pair(150, dtype, mfma=mfma)[1]
     g1.set_option(3, 0)
     ref2, _ = make_pair(150, dtype, mfma=mfma)
     step(ref2, g1)
     mu1, S1 = gpu_state(g1)
-    assert relf(mu1, mu) < t["mu"] * 5 and relf(S1, S) < t["S"]
+    assert bound("mu1, mu", relf(mu1, mu), t["mu"] * 5) and bound("S1, S", relf(S1, S), t["S"])
     vis, z = step(ref, g, seed=77)
     mu, S = gpu_state(g)
-    assert relf(mu, ref.mu) < t["mu"] * 20 and relf(S, ref.Sigma) < t["S"] * 5
+    assert bound("mu, ref.mu #2", relf(mu, ref.mu), t["mu"] * 20) and bound("S, ref.Sigma #2", relf(S, ref.Sigma), t["S"] * 5)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -467,9 +597,11 @@ def test_dynamic_resize_stream(dtype):
             pos, cod = g.featureLayout()
             assert list(pos) == [ft.position_in_state for ft in ref.features]
         mu, S = gpu_state(g)
+        pad, asym, big = g.checkInvariants()                 # capacity 80 > N: the padding must stay exactly zero
+        assert pad == 0.0 and asym <= 2e-6 * big, (frame, pad, asym, big)     # (the injected oracle Sigma is asymmetric at 1e-7)
         # free-running: rounding differences accumulate over the frames (fp32), none in fp64
-        assert relf(mu, ref.mu) < t["mu"] * (50 if dtype == np.float32 else 1e3), frame
-        assert relf(S, ref.Sigma) < t["S"] * (10 if dtype == np.float32 else 1e2), frame
+        assert bound("mu, ref.mu", relf(mu, ref.mu), t["mu"] * (50 if dtype == np.float32 else 1e3)), frame
+        assert bound("S, ref.Sigma", relf(S, ref.Sigma), t["S"] * (10 if dtype == np.float32 else 1e2)), frame
     assert g.numOfFeatures() == 64
 
 
@@ -502,7 +634,7 @@ def test_mid_size_chunked_equals_serial(n_feat, m_meas, plane):
     # (the plane rows pull this camera far from its linearisation point: an ill-conditioned step that
     # amplifies fp32 rounding differences between the two schedules)
     tol = 2e-4 if plane else 1e-5
-    assert relf(mu_a, mu_b) < tol and relf(S_a, S_b) < 10 * tol
+    assert bound("mu_a, mu_b", relf(mu_a, mu_b), tol) and bound("S_a, S_b", relf(S_a, S_b), 10 * tol)
     assert np.abs(S_a - S_a.T).max() <= 1e-6 * np.abs(S_a).max()
 
 
@@ -595,7 +727,7 @@ def test_largest_config_n4000_properties():
     d = np.diag(S)
     assert np.all(d > 0) and np.all(d[14:614] <= d_pred * (1 + 1e-5))
     far = f.getSigmaBlock(24014 - 300, 0, 300, 300)          # a block far from the diagonal against its mirror
-    assert relf(far, f.getSigmaBlock(0, 24014 - 300, 300, 300).T) < 1e-6
+    assert bound("far, f.getSigmaBlock(0, 24014 - 300, 300, 300).T", relf(far, f.getSigmaBlock(0, 24014 - 300, 300, 300).T), 1e-6)
     f.removeFeatures([5, 1999, 3999])                        # one compaction pass over 2.3 GB
     assert f.numOfFeatures() == N - 3 and f.stateDim() == 14 + 6 * (N - 3)
     f.predict()

@@ -28,9 +28,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-def relf(a, b):
-    return float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) /
-                 max(np.linalg.norm(np.asarray(b, np.float64)), 1e-300))
+from helpers import bound, relf  # noqa: E402
 
 
 def reference_run(n_feat, frames, dtype):
@@ -73,8 +71,8 @@ def test_sharded_orchestration_matches_unsharded_oracle_gloo(world):
     seen = np.zeros(ref.n, bool)
     for rank in range(world):
         mu, rows, S_rows = out[rank]
-        assert relf(mu, ref.mu) < 1e-9
-        assert relf(S_rows, ref.Sigma[rows]) < 1e-8
+        assert bound("mu, ref.mu", relf(mu, ref.mu), 1e-9)
+        assert bound("S_rows, ref.Sigma[rows]", relf(S_rows, ref.Sigma[rows]), 1e-8)
         seen[rows] = True
     assert seen.all()                      # the panels cover every row of Sigma
 
@@ -155,9 +153,9 @@ def test_hip_shard_world1_matches_plain_path():
     for k in range(frames):
         step.step(d_z[k].data_ptr())
     flt.synchronize()
-    assert relf(flt.getFullState(), mu_p) < 1e-5
-    assert relf(flt.getFullSigma(), S_p) < 2e-4
-    assert relf(flt.getFullSigma(), ref.Sigma) < 1e-3
+    assert bound("flt.getFullState(), mu_p", relf(flt.getFullState(), mu_p), 1e-5)
+    assert bound("flt.getFullSigma(), S_p", relf(flt.getFullSigma(), S_p), 2e-4)
+    assert bound("flt.getFullSigma(), ref.Sigma", relf(flt.getFullSigma(), ref.Sigma), 1e-3)
 
 
 @pytest.mark.gpu
@@ -170,8 +168,8 @@ def test_hip_shard_two_ranks_on_one_gpu_match_plain_path():
     mp.spawn(_gpu_worker, args=(2, free_port(), n_feat, frames, z_np, out), nprocs=2, join=True)
     for rank in range(2):
         mu, rows, S_rows = out[rank]
-        assert relf(mu, mu_p) < 1e-5
-        assert relf(S_rows, S_p[rows]) < 2e-4
+        assert bound("mu, mu_p", relf(mu, mu_p), 1e-5)
+        assert bound("S_rows, S_p[rows]", relf(S_rows, S_p[rows]), 2e-4)
 
 
 @pytest.mark.gpu
@@ -191,8 +189,8 @@ def test_hip_shard_four_ranks_mid_size_match_plain_path():
     for rank in range(world):
         mu, rows, S_rows = out[rank]
         assert np.all(np.isfinite(mu))
-        assert relf(mu, mu_p) < 2e-5
-        assert relf(S_rows, S_p[rows]) < 5e-4
+        assert bound("mu, mu_p", relf(mu, mu_p), 2e-5)
+        assert bound("S_rows, S_p[rows]", relf(S_rows, S_p[rows]), 5e-4)
 
 
 @pytest.mark.gpu

@@ -1,13 +1,13 @@
 #!/bin/bash
 # PMC passes over tools/gemm_bench (per-dispatch counters of the tile GEMM variants)
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R="${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set (run under gpurun)}"
 i=0
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS" \
            "GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_ADDR_CONFLICT"; do
   i=$((i+1))
-  rocprofv3 --pmc $set -d $R/gpurun_out/pmc_gemm_$i -o p --output-format csv -- $R/tools/gemm_bench > /dev/null 2>&1
+  rocprofv3 --pmc $set -d "$R/gpurun_out/pmc_gemm_$i" -o p --output-format csv -- "$R/tools/gemm_bench" > /dev/null 2>&1
 done
 python3 - <<'PY'
 import csv, glob, os, collections
