@@ -95,12 +95,10 @@ _PROTOS = {
     "ekf_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "ekf_profile_reset": (C.c_int, [_P]),
     "ekf_profile_work": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
-    "ekf_shard_configure": (C.c_int, [_P, C.c_int, C.c_int]),
-    "ekf_shard_get_view": (C.c_int, [_P, _P]),
-    "ekf_shard_predict": (C.c_int, [_P, _P, _P, C.c_int]),
-    "ekf_shard_innovation": (C.c_int, [_P, _P, C.c_int, C.c_int]),
-    "ekf_shard_factor_solve": (C.c_int, [_P]),
-    "ekf_shard_downdate": (C.c_int, [_P]),
+    "ekf_shard_configure": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
+    "ekf_shard_get_info": (C.c_int, [_P, _P]),
+    "ekf_shard_update": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
+    "ekf_shard_rebalance": (C.c_int, [_P]),
     "ekf_device_mu": (_P, [_P]),
     "ekf_device_sigma": (_P, [_P, C.POINTER(C.c_int)]),
 }

@@ -16,6 +16,7 @@
 #include "ekf_image.hpp"
 #include "ekf_split.hpp"
 #include "ekf_kernels.hpp"
+#include "ekf_shard.hpp"
 
 namespace ekf {
 
@@ -40,6 +41,10 @@ enum KernelId : int {
   KID_COMPACT,
   KID_MISC,
   KID_WUPDATE,
+  KID_GATHER_H,
+  KID_GATHER_S,
+  KID_GATHER_V,
+  KID_GATHER_SIGMA,
   KID_COUNT
 };
 
@@ -48,7 +53,7 @@ static const char* kKernelNames[KID_COUNT] = {
     "innovation",      "sigma_ht",         "innovation_cov",      "chol_diag",
     "chol_panel",      "chol_trailing",    "state_update",        "downdate_syrk",
     "solve_trmm",      "normalize_quat",  "add_feature",      "compact_transform",   "misc",
-    "w_update"};
+    "w_update", "allgather_h", "allgather_s", "allgather_v", "allgather_sigma"};
 
 static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
@@ -95,12 +100,10 @@ struct FilterBase {
   virtual int get_patch(int, int, unsigned char*) = 0;
   virtual int blur_predictions(void*) = 0;
   virtual int find_matches(double, void*, unsigned char*, float*) = 0;
-  virtual int shard_configure(int, int) = 0;
-  virtual int shard_view(ekf_shard_view*) = 0;
-  virtual int shard_predict(const void*, const void*, int) = 0;
-  virtual int shard_innovation(const void*, int, int) = 0;
-  virtual int shard_factor_solve() = 0;
-  virtual int shard_downdate() = 0;
+  virtual int shard_configure(int, int, ekf_allgather_fn, void*) = 0;
+  virtual int shard_info(ekf_shard_info*) = 0;
+  virtual int shard_update(const void*, const int*, int, int) = 0;
+  virtual int shard_rebalance() = 0;
 };
 
 #define HIPCHK(expr)                                                                         \
@@ -219,7 +222,7 @@ struct Filter : FilterBase {
                     d_flags, d_cflag, d_Jy, d_Yxyz, d_map_src, d_map_conv, d_Y, d_W, d_V, d_Dinv, d_z, d_midx,
                     d_status, d_tmp, d_K, d_tilemap, d_counters, d_ibuf, d_rmask, d_pts,
                     d_frame, d_patch[0], d_patch[1], d_mpatch[0], d_mpatch[1], d_hb, d_zm, d_found, d_score, d_keep,
-                    d_Vs[0], d_Vs[1], d_Vs[2]};
+                    d_Vs[0], d_Vs[1], d_Vs[2], d_stage_send, d_stage_recv};
     for (void* p : ptrs) if (p) hipFree(p);
     if (own_stream && stream) hipStreamDestroy(stream);
     if (stream_b) hipStreamDestroy(stream_b);
@@ -492,6 +495,7 @@ struct Filter : FilterBase {
     coding.push_back(0);
     N += 1;
     n += 6;
+    shard_after_add();
     extent[cur] = std::max(extent[cur], n);
     layout_dirty = true;
     have_meas = false;
@@ -662,6 +666,7 @@ struct Filter : FilterBase {
     pos.swap(npos); coding.swap(ncoding);
     N = (int)pos.size();
     n = n_new;
+    shard_after_compact(rm);
     layout_dirty = true;
     have_meas = false;
     return EKF_OK;
@@ -680,6 +685,7 @@ struct Filter : FilterBase {
 
   int convert(int index, bool all) override {
     HIPCHK(hipSetDevice(device));
+    if (sh_on) return shard_convert(index, all);
     if (!all && (index < 0 || index >= N)) { err = "feature index out of range"; return -EKF_ERR_ARG; }
     if (N == 0) return 0;
     int rc = sync_layout();
@@ -716,6 +722,7 @@ struct Filter : FilterBase {
 
   int predict(const void* tc, const void* rc_, int vcontrol) override {
     HIPCHK(hipSetDevice(device));
+    if (sh_on) return shard_predict(tc, rc_, vcontrol);
     MotionArgs a;
     a.dT = dT;
     const T* t = static_cast<const T*>(tc);
@@ -993,9 +1000,58 @@ struct Filter : FilterBase {
     return EKF_OK;
   }
 
+  // Block steps [step0, step1) of the serial chain of chunk [c0, c1) on stream sc_: diagonal factor, panel (rows
+  // below the block + the chunk's identity-strip rows), trailing update (strip tiles stop at c1).
+  void chain_steps(int step0, int step1, int c0, int c1, int m, int m_pad, hipStream_t sc_) {
+    const int nb = NB();
+    T* Y = d_Y;
+    for (int step = step0; step < step1; ++step) {
+      const int j = step * nb;
+      T* Ajj = Y + (size_t)j * ldy + j;
+      T* Dj = d_Dinv + (size_t)step * nb * nb;
+      {
+        Scope sc(this, KID_CHOL_DIAG, sc_);
+        if (nb == 128) {
+          if constexpr (kIsF32)
+            k_chol_diag_packed<><<<1, 512, 0, sc_>>>(Ajj, ldy, Dj, d_status, std::max(1, std::min(8, (m - j + 15) / 16)));
+        } else {
+          if constexpr (!kIsF32) {
+            if (opt_mfma)
+              k_chol_diag_packed_f64<<<1, 512, 0, sc_>>>(Ajj, ldy, Dj, d_status, std::max(1, std::min(4, (m - j + 15) / 16)));
+            else
+              k_chol_diag<T, 64><<<1, 512, diag_lds(64), sc_>>>(Ajj, ldy, Dj, d_status);
+          } else {
+            k_chol_diag<T, 64><<<1, 512, diag_lds(64), sc_>>>(Ajj, ldy, Dj, d_status);
+          }
+        }
+      }
+      // rows that change at this step: S rows below the diagonal block, then strip rows [0, r0 - c0)
+      // (Z rows c0..r0 of this chunk): contiguous, m_pad - c0 of them starting at row r0
+      const int r0 = j + nb;
+      const int vrows = m_pad - c0;
+      {
+        Scope sc(this, KID_CHOL_PANEL, sc_);                 // P = Y[r0.., j:j+nb] * Linv_jj^T, in place
+        T* P = Y + (size_t)r0 * ldy + j;
+        launch_panel(P, Dj, vrows, sc_);
+      }
+      if (r0 < m_pad) {
+        Scope sc(this, KID_CHOL_TRAILING, sc_);              // Y[r0.., r0:] -= P P_S^T; strip rows stop at c1
+        const T* P = Y + (size_t)r0 * ldy + j;
+        T* C = Y + (size_t)r0 * ldy + r0;
+        gemm<ROLE_TRAILING, false, 64, 64>(P, ldy, P, ldy, C, ldy, vrows, m_pad - r0, nb, T(-1), T(1), 1, r0, r0, 0, 0,
+                                           sc_, nullptr, 0, m_pad, c1);
+      }
+    }
+  }
+
   // ---- a8-a11 update ---------------------------------------------------------------------
   int update(const void* z, const int* idx, int M, int plane, bool on_device) override {
     HIPCHK(hipSetDevice(device));
+    if (sh_on) {
+      if (on_device) FAIL(EKF_ERR_UNSUPPORTED, "sharded filter: the measured list must be on the host (ekf_shard_update / ekf_update)");
+      if (M > 0 && z) HIPCHK(hipMemcpyAsync(d_z, z, (size_t)2 * M * sizeof(T), hipMemcpyHostToDevice, stream));
+      return shard_update(d_z, idx, M, plane);
+    }
     if (M < 0 || M > N) FAIL(EKF_ERR_ARG, "M out of range");
     if (M == 0 && !plane) return EKF_OK;
     if (!have_meas) FAIL(EKF_ERR_STATE, "ekf_update needs the h/H of ekf_predict or ekf_measure");
@@ -1015,7 +1071,7 @@ struct Filter : FilterBase {
       } else {
         HIPCHK(hipMemcpyAsync(d_z, z, (size_t)2 * M * sizeof(T), hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemcpyAsync(d_midx, idx, (size_t)M * sizeof(int), hipMemcpyHostToDevice, stream));
-        sh_ident = -1;
+        sh_list.clear();
       }
     }
     const int nb = NB();
@@ -1060,43 +1116,8 @@ struct Filter : FilterBase {
         HIPCHK(hipStreamWaitEvent(stream_c, ev_chain[0], 0));      // recorded below, after chunk 0
         c_inflight = true;
       }
-      for (; step < cend[gi]; ++step) {
-        const int j = step * nb;
-        T* Ajj = Y + (size_t)j * ldy + j;
-        T* Dj = d_Dinv + (size_t)step * nb * nb;
-        {
-          Scope sc(this, KID_CHOL_DIAG, sc_);
-          if (nb == 128) {
-            if constexpr (kIsF32)
-              k_chol_diag_packed<><<<1, 512, 0, sc_>>>(Ajj, ldy, Dj, d_status, std::max(1, std::min(8, (m - j + 15) / 16)));
-          } else {
-            if constexpr (!kIsF32) {
-              if (opt_mfma)
-                k_chol_diag_packed_f64<<<1, 512, 0, sc_>>>(Ajj, ldy, Dj, d_status, std::max(1, std::min(4, (m - j + 15) / 16)));
-              else
-                k_chol_diag<T, 64><<<1, 512, diag_lds(64), sc_>>>(Ajj, ldy, Dj, d_status);
-            } else {
-              k_chol_diag<T, 64><<<1, 512, diag_lds(64), sc_>>>(Ajj, ldy, Dj, d_status);
-            }
-          }
-        }
-        // rows that change at this step: S rows below the diagonal block, then strip rows [0, r0 - c0)
-        // (Z rows c0..r0 of this chunk): contiguous, m_pad - c0 of them starting at row r0
-        const int r0 = j + nb;
-        const int vrows = m_pad - c0;
-        {
-          Scope sc(this, KID_CHOL_PANEL, sc_);                 // P = Y[r0.., j:j+nb] * Linv_jj^T, in place
-          T* P = Y + (size_t)r0 * ldy + j;
-          launch_panel(P, Dj, vrows, sc_);
-        }
-        if (r0 < m_pad) {
-          Scope sc(this, KID_CHOL_TRAILING, sc_);              // Y[r0.., r0:] -= P P_S^T; strip rows stop at c1
-          const T* P = Y + (size_t)r0 * ldy + j;
-          T* C = Y + (size_t)r0 * ldy + r0;
-          gemm<ROLE_TRAILING, false, 64, 64>(P, ldy, P, ldy, C, ldy, vrows, m_pad - r0, nb, T(-1), T(1), 1, r0, r0, 0, 0,
-                                             sc_, nullptr, 0, m_pad, c1);
-        }
-      }
+      chain_steps(step, cend[gi], c0, c1, m, m_pad, sc_);
+      step = cend[gi];
       const int width = c1 - c0;
       // the last chunk has nothing left to overlap with: it runs on the main stream, on every CU
       const bool overlap = (stream_b != nullptr) && (gi + 1 < nchunks);
@@ -1245,7 +1266,7 @@ struct Filter : FilterBase {
     for (int k = 0; k < M; ++k)
       if (idx[k] < 0 || idx[k] >= N) FAIL(EKF_ERR_ARG, "feature index out of range");
     if (M > 0) HIPCHK(hipMemcpyAsync(d_midx, idx, (size_t)M * sizeof(int), hipMemcpyHostToDevice, stream));
-    sh_ident = -1;
+    sh_list.clear();
     int m = 0, m_pad = 0;
     int rc = build_innovation(M, plane, false, &m, &m_pad);
     if (rc) return rc;
@@ -1404,7 +1425,7 @@ struct Filter : FilterBase {
     HIPCHK(hipMemcpyAsync(d_z, z, (size_t)2 * M * sizeof(T), hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(d_midx, idx, (size_t)M * sizeof(int), hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(d_tmp, cam_before, 7 * sizeof(T), hipMemcpyHostToDevice, stream));
-    sh_ident = -1;
+    sh_list.clear();
     if (!d_ibuf) HIPCHK(hipMalloc(&d_ibuf, (size_t)std::max(capN, 1) * 3 * sizeof(int)));
     unsigned char* d_out = reinterpret_cast<unsigned char*>(d_ibuf);
     {
@@ -1460,7 +1481,7 @@ struct Filter : FilterBase {
       if (idx[k] < 0 || idx[k] >= N) FAIL(EKF_ERR_ARG, "feature index out of range");
     HIPCHK(hipMemcpyAsync(d_z, z, (size_t)2 * M * sizeof(T), hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(d_midx, idx, (size_t)M * sizeof(int), hipMemcpyHostToDevice, stream));
-    sh_ident = -1;
+    sh_list.clear();
     int m = 0, m_pad = 0;
     { int rcs = ensure_sd(); if (rcs) return rcs; }
     int rc = build_innovation(M, 0, false, &m, &m_pad);       // W = Sigma H^T for the listed features
@@ -1495,39 +1516,166 @@ struct Filter : FilterBase {
   }
 
   // ---- multi-GPU row-panel sharding ------------------------------------------------
-  int sh_rank = 0, sh_world = 1, sh_f0 = 0, sh_f1 = 0, sh_r0 = 0, sh_r1 = 0, sh_p0 = 0, sh_prows = 0;
-  int sh_m = 0, sh_m_pad = 0, sh_plane = 0, sh_stage = 0, sh_ident = -1;
+  // One process per GPU; every rank holds the same feature list and runs every resize operation, rank g OWNS the
+  // contiguous features [sh_fb[g], sh_fb[g+1]) and keeps valid: the rows of Sigma / W / V of those features (all
+  // columns) and the camera rows; mu is replicated.  Every exchange is an all-gather of equal-sized staging slots
+  // through the host's collective (sh_ag: RCCL via torch.distributed, or a C++ node's own ncclAllGather).
+  bool sh_on = false;
+  int sh_rank = 0, sh_world = 1;
+  std::vector<int> sh_fb;                                  // feature boundaries of the ranks, world + 1 entries
+  ekf_allgather_fn sh_ag = nullptr;
+  void* sh_ctx = nullptr;
+  T *d_stage_send = nullptr, *d_stage_recv = nullptr;
+  size_t stage_slot = 0;                                   // scalars per slot the staging buffers hold
+  int sh_rebalances = 0;
+  std::vector<int> sh_list;                                // host copy of the measured list resident in d_midx
+  double sh_imbalance_limit = 1.125;                       // re-partition when a rank owns > 1.125 x the mean rows
 
-  int shard_configure(int rank, int world) override {
-    if (world < 1 || rank < 0 || rank >= world) FAIL(EKF_ERR_ARG, "bad rank / world");
-    if (N == 0 || N % world != 0) FAIL(EKF_ERR_UNSUPPORTED, "sharding needs N > 0 divisible by the world size");
-    for (int i = 0; i < N; ++i)
-      if (coding[i] != 0) FAIL(EKF_ERR_UNSUPPORTED, "sharding supports inverse-depth features only (round 1)");
-    sh_rank = rank; sh_world = world;
-    sh_f0 = N / world * rank; sh_f1 = N / world * (rank + 1);
-    sh_r0 = pos[sh_f0]; sh_r1 = sh_r0 + 6 * (sh_f1 - sh_f0);
-    const int nb = NB();
-    // tile-padded row panel [sh_p0, sh_p0 + sh_prows): covers the own rows and possibly a few foreign
-    // ones (whose results nobody reads).  A panel that starts inside the first tile is extended to
-    // row 0 so that it never half-overlaps the replicated camera tile.
-    sh_prows = round_up(sh_r1 - sh_r0, nb);
-    sh_p0 = std::min(sh_r0, n_pad - sh_prows);
-    if (sh_p0 < nb) { sh_p0 = 0; sh_prows = round_up(sh_r1, nb); }
-    if (sh_p0 < 0 || sh_p0 + sh_prows > n_pad) FAIL(EKF_ERR_UNSUPPORTED, "panel does not fit");
-    sh_stage = 0;
+  int own_f0() const { return sh_fb[sh_rank]; }
+  int own_f1() const { return sh_fb[sh_rank + 1]; }
+  int row_of_feature(int f) const { return f < N ? pos[f] : n; }
+
+  // boundaries that balance the ROWS (6 per inverse-depth, 3 per XYZ feature) of the current map
+  void partition_by_rows() {
+    sh_fb.assign(sh_world + 1, N);
+    sh_fb[0] = 0;
+    const long long rows = n - camera_dim;
+    int f = 0;
+    for (int g = 1; g < sh_world; ++g) {
+      const long long target = rows * g / sh_world;
+      while (f < N && (long long)(pos[f] - camera_dim) < target) ++f;
+      sh_fb[g] = f;
+    }
+  }
+
+  int ensure_stage(size_t slot_elems) {
+    if (slot_elems <= stage_slot) return EKF_OK;
+    HIPCHK(hipStreamSynchronize(stream));
+    if (stream_b) HIPCHK(hipStreamSynchronize(stream_b));
+    if (d_stage_send) HIPCHK(hipFree(d_stage_send));
+    if (d_stage_recv) HIPCHK(hipFree(d_stage_recv));
+    d_stage_send = d_stage_recv = nullptr;
+    slot_elems = (slot_elems + 63) / 64 * 64;
+    HIPCHK(hipMalloc(&d_stage_send, slot_elems * sizeof(T)));
+    HIPCHK(hipMalloc(&d_stage_recv, slot_elems * sizeof(T) * sh_world));
+    stage_slot = slot_elems;
     return EKF_OK;
   }
-  int shard_view(ekf_shard_view* v) override {
-    if (!v) FAIL(EKF_ERR_ARG, "null view");
-    v->rank = sh_rank; v->world = sh_world; v->N = N; v->f_begin = sh_f0; v->f_end = sh_f1;
-    v->camera_dim = camera_dim; v->rows_per_rank = sh_r1 - sh_r0;
-    v->m = sh_m; v->m_pad = sh_m_pad; v->ldy = ldy;
-    v->d_h = d_h; v->d_Hc = d_Hc; v->d_Hf = d_Hf; v->d_flags = d_flags; v->d_S = d_Y; v->d_V = d_V;
+
+  // the collective: slot g of d_stage_recv <- d_stage_send of rank g, ordered on stream `st`
+  int all_gather(size_t slot_elems, hipStream_t st) {
+    if (sh_world == 1) return EKF_OK;
+    if (!sh_ag) FAIL(EKF_ERR_STATE, "sharded filter without an all-gather callback (ekf_shard_configure)");
+    const int rc = sh_ag(sh_ctx, d_stage_send, d_stage_recv, slot_elems * sizeof(T), st);
+    if (rc != 0) FAIL(EKF_ERR_DEVICE, "the all-gather callback reported a failure");
     return EKF_OK;
   }
-  int shard_predict(const void* tc, const void* rc_, int vcontrol) override {
+
+  // rows [tab.start[g], +tab.count[g]) x columns [col0, col0 + ncols) of `buf` (row stride ldb): own range out,
+  // everybody else's in
+  int exchange_rows(T* buf, int ldb, const ShardTab& tab, int col0, int ncols, hipStream_t st, int kid) {
+    if (sh_world == 1) return EKF_OK;
+    int maxrows = 0;
+    for (int g = 0; g < sh_world; ++g) maxrows = std::max(maxrows, tab.count[g]);
+    if (maxrows == 0) return EKF_OK;
+    const size_t slot = (size_t)maxrows * ncols;
+    int rc = ensure_stage(slot);
+    if (rc) return rc;
+    Scope sc(this, kid, st);
+    const int own = tab.count[sh_rank];
+    const int gx = std::max(1, std::min(8, (ncols / (int)(16 / sizeof(T)) + 255) / 256));
+    if (own > 0)
+      k_pack_rows<T><<<dim3(gx, std::min(own, 65535)), 256, 0, st>>>(buf, ldb, tab.start[sh_rank], own, col0, ncols, d_stage_send);
+    rc = all_gather(slot, st);
+    if (rc) return rc;
+    k_unpack_rows<T><<<dim3(gx, std::min(maxrows, 65535), sh_world), 256, 0, st>>>(d_stage_recv, slot, ncols, buf, ldb, col0, tab);
+    HIPCHK(hipGetLastError());
+    return EKF_OK;
+  }
+
+  ShardTab row_tab() const {                               // state rows owned by every rank
+    ShardTab t{sh_world, sh_rank, {}, {}};
+    for (int g = 0; g < sh_world; ++g) {
+      t.start[g] = row_of_feature(sh_fb[g]);
+      t.count[g] = row_of_feature(sh_fb[g + 1]) - t.start[g];
+    }
+    return t;
+  }
+  ShardTab feature_tab() const {
+    ShardTab t{sh_world, sh_rank, {}, {}};
+    for (int g = 0; g < sh_world; ++g) { t.start[g] = sh_fb[g]; t.count[g] = sh_fb[g + 1] - sh_fb[g]; }
+    return t;
+  }
+
+  int shard_configure(int rank, int world, ekf_allgather_fn fn, void* ctx) override {
+    if (world < 1 || world > kMaxWorld || rank < 0 || rank >= world) FAIL(EKF_ERR_ARG, "bad rank / world");
+    if (world > 1 && !fn) FAIL(EKF_ERR_ARG, "world > 1 needs an all-gather callback");
     HIPCHK(hipSetDevice(device));
-    if (sh_f1 <= sh_f0) FAIL(EKF_ERR_STATE, "ekf_shard_configure first");
+    sh_rank = rank; sh_world = world; sh_ag = fn; sh_ctx = ctx;
+    sh_on = true;
+    // every rank was built by the same calls, so all of Sigma is valid everywhere right now: any partition will do
+    partition_by_rows();
+    have_meas = false;
+    return EKF_OK;
+  }
+
+  int shard_info(ekf_shard_info* o) override {
+    if (!o) FAIL(EKF_ERR_ARG, "null info");
+    memset(o, 0, sizeof(*o));
+    o->rank = sh_rank; o->world = sh_world; o->N = N; o->state_dim = n;
+    if (sh_on) {
+      o->f_begin = own_f0(); o->f_end = own_f1();
+      o->row_begin = row_of_feature(own_f0()); o->row_end = row_of_feature(own_f1());
+      int mx = 0;
+      for (int g = 0; g < sh_world; ++g) mx = std::max(mx, row_of_feature(sh_fb[g + 1]) - row_of_feature(sh_fb[g]));
+      o->max_rows_any_rank = mx;
+    } else {
+      o->f_end = N; o->row_begin = camera_dim; o->row_end = n; o->max_rows_any_rank = n - camera_dim;
+    }
+    o->rebalances = sh_rebalances;
+    return EKF_OK;
+  }
+
+  // ownership follows the resize operations every rank executes identically
+  void shard_after_add() { if (sh_on) sh_fb[sh_world] = N; }
+  void shard_after_compact(const std::vector<char>& rm) {
+    if (!sh_on) return;
+    std::vector<int> kept_before(rm.size() + 1, 0);
+    for (size_t i = 0; i < rm.size(); ++i) kept_before[i + 1] = kept_before[i] + (rm[i] ? 0 : 1);
+    for (int g = 0; g <= sh_world; ++g) sh_fb[g] = kept_before[std::min<size_t>(sh_fb[g], rm.size())];
+  }
+
+  // Makes every row of Sigma valid on every rank (all-gather of the row panels, in column blocks) and re-partitions
+  // the features so that the rows are balanced again.  Also the sync point before reading foreign rows of Sigma.
+  int shard_rebalance() override {
+    HIPCHK(hipSetDevice(device));
+    if (!sh_on) FAIL(EKF_ERR_STATE, "ekf_shard_configure first");
+    if (sh_world > 1 && N > 0) {
+      const ShardTab tab = row_tab();
+      const int cw = 4096;                                 // column block: bounds the staging buffers
+      const int vec = 16 / (int)sizeof(T);
+      for (int c0 = 0; c0 < n; c0 += cw) {
+        const int nc = round_up(std::min(cw, n - c0), vec);
+        int rc = exchange_rows(S(), ld, tab, c0, nc, stream, KID_GATHER_SIGMA);
+        if (rc) return rc;
+      }
+    }
+    partition_by_rows();
+    ++sh_rebalances;
+    have_meas = false;
+    return EKF_OK;
+  }
+
+  bool shard_needs_rebalance() const {
+    if (sh_world == 1 || N == 0) return false;
+    int mx = 0;
+    for (int g = 0; g < sh_world; ++g) mx = std::max(mx, row_of_feature(sh_fb[g + 1]) - row_of_feature(sh_fb[g]));
+    const double mean = double(n - camera_dim) / sh_world;
+    return mx > sh_imbalance_limit * mean + 6.0;
+  }
+
+  int shard_predict(const void* tc, const void* rc_, int vcontrol) {
+    if (shard_needs_rebalance()) { int rr = shard_rebalance(); if (rr) return rr; }
     MotionArgs a;
     a.dT = dT;
     const T* t = static_cast<const T*>(tc);
@@ -1537,149 +1685,150 @@ struct Filter : FilterBase {
     int rc = sync_layout();
     if (rc) return rc;
     { Scope sc(this, KID_PREDICT_CAMERA); k_predict_camera<T><<<1, 64, 0, stream>>>(mu(), d_scr, a); }
+    have_motion = true;
     {
       // rows 0..12 are replicated; the column strip of foreign rows works on stale data nobody reads
       Scope sc(this, KID_PROPAGATE_STRIPS);
       k_strip_congruence<T, 13><<<(2 * n + 255) / 256, 256, 0, stream>>>(S(), ld, n, 0, d_scr + SCR_FT, d_scr + SCR_Q);
     }
-    {
+    const int f0 = own_f0(), f1 = own_f1();
+    if (f1 > f0) {
       Scope sc(this, KID_MEASURE);
-      const int cnt = sh_f1 - sh_f0;
-      k_measure<T><<<(cnt + 63) / 64, 64, 0, stream>>>(mu(), d_pos, d_coding, sh_f0, sh_f1, cam, d_h, d_Hc, d_Hf,
-                                                        d_flags);
+      k_measure<T><<<(f1 - f0 + 63) / 64, 64, 0, stream>>>(mu(), d_pos, d_coding, f0, f1, cam, d_h, d_Hc, d_Hf, d_flags);
     }
     HIPCHK(hipGetLastError());
+    if (sh_world > 1 && N > 0) {                           // "reassemble H": h, compact Jacobians, flags of every feature
+      const ShardTab tab = feature_tab();
+      int mx = 0;
+      for (int g = 0; g < sh_world; ++g) mx = std::max(mx, tab.count[g]);
+      const size_t slot = (size_t)mx * kFeatRec;
+      rc = ensure_stage(slot);
+      if (rc) return rc;
+      Scope sc(this, KID_GATHER_H);
+      if (f1 > f0)
+        k_pack_features<T><<<((f1 - f0) * kFeatRec + 255) / 256, 256, 0, stream>>>(d_h, d_Hc, d_Hf, d_flags, f0, f1 - f0, d_stage_send);
+      rc = all_gather(slot, stream);
+      if (rc) return rc;
+      k_unpack_features<T><<<dim3((mx * kFeatRec + 255) / 256, sh_world), 256, 0, stream>>>(d_stage_recv, slot, d_h, d_Hc, d_Hf, d_flags, tab);
+      HIPCHK(hipGetLastError());
+    }
     have_update = false;
-    have_meas = false;
-    sh_stage = 1;
+    have_meas = true;
+    have_sd = false;
     return EKF_OK;
   }
-  int shard_innovation(const void* dz, int M, int plane) override {
+
+  // The sharded EKF update block for the measured list `idx` (host, strictly ascending), z resident on the device.
+  int shard_update(const void* dz, const int* idx, int M, int plane) override {
     HIPCHK(hipSetDevice(device));
-    if (sh_stage != 1) FAIL(EKF_ERR_STATE, "ekf_shard_innovation follows ekf_shard_predict (+ gather of h / H)");
-    if (M != N) FAIL(EKF_ERR_UNSUPPORTED, "sharded update measures every feature (M = N) in round 1");
-    HIPCHK(hipMemcpyAsync(d_z, dz, (size_t)2 * M * sizeof(T), hipMemcpyDeviceToDevice, stream));
-    if (sh_ident != M) {                                   // identity measured list, uploaded once
-      std::vector<int> ident(M);
-      for (int i = 0; i < M; ++i) ident[i] = i;
-      HIPCHK(hipMemcpyAsync(d_midx, ident.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice, stream));
-      HIPCHK(hipStreamSynchronize(stream));
-      sh_ident = M;
+    if (!sh_on) FAIL(EKF_ERR_STATE, "ekf_shard_configure first");
+    if (M < 0 || M > N) FAIL(EKF_ERR_ARG, "M out of range");
+    if (M == 0 && !plane) return EKF_OK;
+    if (!have_meas) FAIL(EKF_ERR_STATE, "the sharded update needs the h / H of the sharded predict");
+    if (M > 0 && (!dz || !idx)) FAIL(EKF_ERR_ARG, "z / indices are NULL");
+    for (int k = 0; k < M; ++k) {
+      if (idx[k] < 0 || idx[k] >= N) FAIL(EKF_ERR_ARG, "feature index out of range");
+      if (k > 0 && idx[k - 1] >= idx[k]) FAIL(EKF_ERR_ARG, "measured indices must be strictly ascending");
     }
+    if (M > 0 && ((int)sh_list.size() != M || memcmp(sh_list.data(), idx, (size_t)M * sizeof(int)) != 0)) {
+      sh_list.assign(idx, idx + M);
+      HIPCHK(hipMemcpyAsync(d_midx, sh_list.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice, stream));
+    }
+    sh_list.clear();
+    const T* d_zz = static_cast<const T*>(dz);
     const int nb = NB();
-    const int m = 2 * M + (plane ? 3 : 0);
-    const int m_pad = round_up(m, nb);
+    const int m = 2 * M + (plane ? 3 : 0), m_pad = round_up(m, nb);
     const int npad_live = round_up(n, nb);
     T* nu_row = d_W + (size_t)ldy * npad_live;
     if (w_zeroed_n != n) {
       HIPCHK(hipMemsetAsync(d_W + (size_t)n * ldy, 0, (size_t)(npad_live - n + nb) * ldy * sizeof(T), stream));
       w_zeroed_n = n;
     }
+    // own state rows, and the tile-padded panel [p0, p0 + prows) the tile GEMMs run on: it covers the own rows and,
+    // at its ends, a few foreign ones (whose results nobody reads and the next gather overwrites); it never reaches
+    // past the padded live block (row npad_live of W / V is the nu / y row)
+    const int f0 = own_f0(), f1 = own_f1();
+    const int r0 = row_of_feature(f0), r1 = row_of_feature(f1);
+    int p0 = 0, prows = 0;
+    if (r1 > r0) {
+      prows = round_up(r1 - r0, nb);
+      p0 = std::min(r0, npad_live - prows);
+      if (p0 < nb) { p0 = 0; prows = std::min(npad_live, round_up(r1, nb)); }
+    }
+    struct Rows { int r0, count; };
+    const Rows ranges[3] = {{0, p0 > 0 || prows == 0 ? nb : 0}, {p0, prows}, {npad_live, nb}};
+    // list positions [k0, k1) of the own measured features (the list is ascending, ownership contiguous)
+    ShardTab stab{sh_world, sh_rank, {}, {}};
+    {
+      int k = 0;
+      for (int g = 0; g < sh_world; ++g) {
+        while (k < M && idx[k] < sh_fb[g]) ++k;
+        int e = k;
+        while (e < M && idx[e] < sh_fb[g + 1]) ++e;
+        stab.start[g] = 2 * k;
+        stab.count[g] = 2 * (e - k);
+        k = e;
+      }
+    }
+    const int k0 = stab.start[sh_rank] / 2, k1 = k0 + stab.count[sh_rank] / 2;
     { Scope sc(this, KID_INNOVATION);
-      k_innovation<T><<<(std::max(m_pad, 64) + 255) / 256, 256, 0, stream>>>(d_z, d_h, d_midx, M, plane, mu(), nu_row, m_pad,
+      k_innovation<T><<<(std::max(m_pad, 64) + 255) / 256, 256, 0, stream>>>(d_zz, d_h, d_midx, M, plane, mu(), nu_row, m_pad,
                                                                           d_counters, N, d_status);
       counter_next = 0; }
     {
-      Scope sc(this, KID_SIGMA_HT);
+      Scope sc(this, KID_SIGMA_HT);                        // W rows {camera, own}
       constexpr int RB = 32;
       dim3 g1((m_pad / 2 + 255) / 256, (camera_dim + RB - 1) / RB);
       k_sigma_ht<T, RB><<<g1, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane, d_W, ldy,
                                               m_pad, 0, camera_dim, N);
-      dim3 g2((m_pad / 2 + 255) / 256, (sh_r1 - sh_r0 + RB - 1) / RB);
-      k_sigma_ht<T, RB><<<g2, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane, d_W, ldy,
-                                              m_pad, sh_r0, sh_r1, N);
+      if (r1 > r0) {
+        dim3 g2((m_pad / 2 + 255) / 256, (r1 - r0 + RB - 1) / RB);
+        k_sigma_ht<T, RB><<<g2, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane, d_W, ldy,
+                                                m_pad, r0, r1, N);
+      }
     }
     {
-      Scope sc(this, KID_INNOVATION_COV);
+      Scope sc(this, KID_INNOVATION_COV);                  // S rows of the own measured features + the plane / padding rows
       constexpr int KB = 8;
-      dim3 grid((m_pad + 255) / 256, std::max(1, (sh_f1 - sh_f0 + KB - 1) / KB) + (m_pad - 2 * M + 7) / 8);
+      dim3 grid((m_pad + 255) / 256, std::max(1, (k1 - k0 + KB - 1) / KB) + (m_pad - 2 * M + 7) / 8);
       k_innovation_cov<T, KB><<<grid, 256, 0, stream>>>(d_W, ldy, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane,
-                                                      T(sigma_pixel_2), T(0.00001), d_Y, m_pad, sh_f0, sh_f1,
+                                                      T(sigma_pixel_2), T(0.00001), d_Y, m_pad, k0, k1,
                                                       static_cast<T*>(nullptr), N);
     }
     HIPCHK(hipGetLastError());
-    sh_m = m; sh_m_pad = m_pad; sh_plane = plane;
-    sh_stage = 2;
-    return EKF_OK;
-  }
-  int shard_factor_solve() override {
-    HIPCHK(hipSetDevice(device));
-    if (sh_stage != 2) FAIL(EKF_ERR_STATE, "ekf_shard_factor_solve follows ekf_shard_innovation (+ gather of S)");
-    const int nb = NB();
-    const int m_pad = sh_m_pad;
-    const int npad_live = round_up(n, nb);
+    int rc = exchange_rows(d_Y, ldy, stab, 0, m_pad, stream, KID_GATHER_S);     // "reassemble S"
+    if (rc) return rc;
+
+    // replicated chain in column chunks, the rank's share of every chunk (solve, W update, gather of V_g, downdate)
+    // beside it on the CU-masked second stream -- the structure of Filter::update
     const int nsteps = m_pad / nb;
-    T* Y = d_Y;
-    T* Zs = d_Y + (size_t)m_pad * ldy;
-    // the chain is replicated on every rank (S is small); chunks of 4 block steps with diagonal-chunk
-    // inverses as in Filter::update, one stream: per chunk the rank solves and right-updates only ITS rows of
-    // [W; nu^T] (camera tile, own row panel, nu block)
-    ChunkTab tab{0, {}};
     int cend[8];
-    {
-      const int want = std::min(8, (nsteps + 3) / 4);
-      int k = 0, prev = 0;
-      for (int g = 0; g < want; ++g) {
-        int e = (g + 1 == want) ? nsteps : std::min(nsteps, 4 * (g + 1));
-        if (e > prev) { cend[k++] = e; prev = e; }
-      }
-      tab.n = k;
-    }
+    const int nchunks = plan_chunks(nsteps, cend);
+    ChunkTab tab{nchunks, {}};
     int strip_rows = 0;
-    for (int g = 0; g < tab.n; ++g) {
+    for (int g = 0; g < nchunks; ++g) {
       tab.end[g] = cend[g] * nb;
       strip_rows = std::max(strip_rows, (cend[g] - (g ? cend[g - 1] : 0)) * nb);
     }
+    T* Y = d_Y;
+    T* Zs = d_Y + (size_t)m_pad * ldy;
     { Scope sc(this, KID_MISC);
       dim3 grid((m_pad + 255) / 256, strip_rows);
       k_set_identity_strip<T><<<grid, 256, 0, stream>>>(Zs, ldy, m_pad, tab); }
-    struct Rows { int r0, count; };
-    const Rows ranges[3] = {{0, sh_p0 > 0 ? nb : 0}, {sh_p0, sh_prows}, {npad_live, nb}};
+    const ShardTab rtab = row_tab();
     int step = 0;
     bool b_inflight = false;
-    for (int gi = 0; gi < tab.n; ++gi) {
+    for (int gi = 0; gi < nchunks; ++gi) {
       const int c0 = step * nb, c1 = cend[gi] * nb, width = c1 - c0;
-      for (; step < cend[gi]; ++step) {
-        const int j = step * nb;
-        T* Ajj = Y + (size_t)j * ldy + j;
-        T* Dj = d_Dinv + (size_t)step * nb * nb;
-        { Scope sc(this, KID_CHOL_DIAG);
-          if (nb == 128) {
-            if constexpr (kIsF32)
-              k_chol_diag_packed<><<<1, 512, 0, stream>>>(Ajj, ldy, Dj, d_status, std::max(1, std::min(8, (sh_m - j + 15) / 16)));
-          } else {
-            if constexpr (!kIsF32) {
-              if (opt_mfma)
-                k_chol_diag_packed_f64<<<1, 512, 0, stream>>>(Ajj, ldy, Dj, d_status, std::max(1, std::min(4, (sh_m - j + 15) / 16)));
-              else
-                k_chol_diag<T, 64><<<1, 512, diag_lds(64), stream>>>(Ajj, ldy, Dj, d_status);
-            } else {
-              k_chol_diag<T, 64><<<1, 512, diag_lds(64), stream>>>(Ajj, ldy, Dj, d_status);
-            }
-          } }
-        const int r0 = j + nb;
-        const int vrows = m_pad - c0;
-        { Scope sc(this, KID_CHOL_PANEL);
-          T* P = Y + (size_t)r0 * ldy + j;
-          launch_panel(P, Dj, vrows, stream); }
-        if (r0 < m_pad) {
-          Scope sc(this, KID_CHOL_TRAILING);
-          const T* P = Y + (size_t)r0 * ldy + j;
-          T* C = Y + (size_t)r0 * ldy + r0;
-          gemm<ROLE_TRAILING, false, 64, 64>(P, ldy, P, ldy, C, ldy, vrows, m_pad - r0, nb, T(-1), T(1), 1, r0, r0, 0, 0,
-                                             nullptr, nullptr, 0, m_pad, c1);
-        }
-      }
-      // the rank's solve / W update of every chunk but the last runs beside the (replicated) chain on the CU-masked
-      // second stream, as in Filter::update -- unless the caller's stream is the legacy default stream, which
-      // synchronises implicitly with every other stream (the two would only take turns)
-      const bool overlap = (stream_b != nullptr) && (stream != nullptr) && (gi + 1 < tab.n);
+      chain_steps(step, cend[gi], c0, c1, m, m_pad, stream);
+      step = cend[gi];
+      const bool overlap = (stream_b != nullptr) && (gi + 1 < nchunks);
       hipStream_t ss = overlap ? stream_b : stream;
       if (overlap) {
         HIPCHK(hipEventRecord(ev_chain[gi], stream));
         HIPCHK(hipStreamWaitEvent(stream_b, ev_chain[gi], 0));
         b_inflight = true;
-      } else if (b_inflight) {
+      } else if (b_inflight) {                             // the last chunk needs every earlier W update and downdate
         HIPCHK(hipEventRecord(ev_b, stream_b));
         HIPCHK(hipStreamWaitEvent(stream, ev_b, 0));
         b_inflight = false;
@@ -1696,45 +1845,71 @@ struct Filter : FilterBase {
                                     m_pad - c1, width, T(-1), T(1), 0, 0, 0, 0, 0, ss);
         }
       }
-    }
-    if (b_inflight) {
-      HIPCHK(hipEventRecord(ev_b, stream_b));
-      HIPCHK(hipStreamWaitEvent(stream, ev_b, 0));
+      rc = exchange_rows(d_V, ldy, rtab, c0, width, ss, KID_GATHER_V);           // every row of V_g on every rank
+      if (rc) return rc;
+      for (int q = 0; q < 2; ++q) {                        // Sigma[rows, :] -= V_g[rows] V_g^T: camera tile, own panel
+        const Rows& rr = ranges[q];
+        if (rr.count == 0) continue;
+        Scope sc(this, KID_DOWNDATE, ss);
+        if (sc.on) prof_work[KID_DOWNDATE] += 2.0 * rr.count * double(n) * (std::min(c1, m) - std::min(c0, m));
+        gemm<ROLE_DOWNDATE, false>(d_V + (size_t)rr.r0 * ldy + c0, ldy, d_V + c0, ldy, S() + (size_t)rr.r0 * ld, ld, rr.count,
+                                   npad_live, width, T(-1), T(1), 0, 0, 0, 0, 0, ss);
+      }
     }
     HIPCHK(hipGetLastError());
-    last_nchunks = tab.n;
-    for (int g = 0; g < tab.n; ++g) last_cend[g] = cend[g];
-    sh_stage = 3;
-    return EKF_OK;
-  }
-  int shard_downdate() override {
-    HIPCHK(hipSetDevice(device));
-    if (sh_stage != 3) FAIL(EKF_ERR_STATE, "ekf_shard_downdate follows ekf_shard_factor_solve (+ gather of V)");
-    const int nb = NB();
-    const int m_pad = sh_m_pad;
-    const int npad_live = round_up(n, nb);
-    const T* V = d_V;
-    const T* yv = d_V + (size_t)npad_live * ldy;
-    { Scope sc(this, KID_STATE_UPDATE);
-      k_state_update<T><<<(n + 3) / 4, 256, 0, stream>>>(mu(), V, ldy, n, yv, m_pad); }
+    last_nchunks = nchunks;
+    for (int g = 0; g < nchunks; ++g) last_cend[g] = cend[g];
     {
-      Scope sc(this, KID_DOWNDATE);     // own row panel and the replicated camera tile, all columns
-      gemm<ROLE_DOWNDATE, false>(V + (size_t)sh_p0 * ldy, ldy, V, ldy, S() + (size_t)sh_p0 * ld, ld, sh_prows, npad_live,
-                                 m_pad, T(-1), T(1), 0, 0, 0, 0);
-      if (sh_p0 > 0)   // a panel that starts at row 0 already contains the camera tile
-        gemm<ROLE_DOWNDATE, false>(V, ldy, V, ldy, S(), ld, nb, npad_live, m_pad, T(-1), T(1), 0, 0, 0, 0);
+      Scope sc(this, KID_STATE_UPDATE);                    // mu is replicated: every rank adds V y over all rows
+      k_state_update<T><<<(n + 7) / 8, 512, 0, stream>>>(mu(), d_V, ldy, n, d_V + (size_t)npad_live * ldy, m_pad, d_scr + SCR_QN);
     }
     {
       Scope sc(this, KID_NORMALIZE);
-      k_normalize_quat<T><<<1, 64, 0, stream>>>(mu(), d_scr);
       k_strip_congruence<T, 4><<<(2 * n + 255) / 256, 256, 0, stream>>>(S(), ld, n, 3, d_scr + SCR_QN,
                                                                        static_cast<const T*>(nullptr));
     }
     HIPCHK(hipGetLastError());
-    last_m = sh_m; last_m_pad = m_pad; last_n = n;
+    last_m = m; last_m_pad = m_pad; last_n = n;
     have_update = true;
-    sh_stage = 0;
+    have_meas = false;
+    ++frame_seq;
     return EKF_OK;
+  }
+
+  // convert2XYZ_ifLinear(All) under sharding: the linearity index needs Sigma(rho, rho) -- known to the owner --
+  // so every rank tests its own features and the flags are gathered before the (identical) compaction pass
+  int shard_convert(int index, bool all) {
+    if (!all && (index < 0 || index >= N)) { err = "feature index out of range"; return -EKF_ERR_ARG; }
+    if (N == 0) return 0;
+    int rc = sync_layout();
+    if (rc) return -rc;
+    k_linearity<T><<<(N + 127) / 128, 128, 0, stream>>>(mu(), S(), ld, d_pos, d_coding, N, d_cflag, d_Jy, d_Yxyz, 0);
+    if (sh_world > 1) {
+      const ShardTab tab = feature_tab();
+      int mx = 0;
+      for (int g = 0; g < sh_world; ++g) mx = std::max(mx, tab.count[g]);
+      const size_t slot = (size_t)mx;
+      rc = ensure_stage(slot);
+      if (rc) return -rc;
+      const int cnt = own_f1() - own_f0();
+      if (cnt > 0) k_pack_flags<T><<<(cnt + 255) / 256, 256, 0, stream>>>(d_cflag, own_f0(), cnt, d_stage_send);
+      rc = all_gather(slot, stream);
+      if (rc) return -rc;
+      k_unpack_flags<T><<<dim3((mx + 255) / 256, sh_world), 256, 0, stream>>>(d_stage_recv, slot, d_cflag, tab);
+    }
+    std::vector<unsigned char> fl(N);
+    if (hipMemcpyAsync(fl.data(), d_cflag, N, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess) { err = "linearity flags D2H failed"; return -EKF_ERR_DEVICE; }
+    std::vector<char> rm(N, 0), cv(N, 0);
+    int cnt = 0;
+    for (int i = 0; i < N; ++i) {
+      if (!all && i != index) continue;
+      if (fl[i] && coding[i] == 0) { cv[i] = 1; ++cnt; }
+    }
+    if (cnt == 0) return 0;
+    rc = compact(rm, cv);
+    if (rc) return -rc;
+    return cnt;
   }
 
   int profile_read(int kid, double* ms, long long* cnt) override {
@@ -1929,12 +2104,16 @@ int ekf_ransac_1point(ekf_filter* f, const void* z, const int* idx, int M, doubl
   IMPL_OR_ARG(f);
   return f->impl->ransac(z, idx, M, thr, counts, inl, best);
 }
-int ekf_shard_configure(ekf_filter* f, int rank, int world) { IMPL_OR_ARG(f); return f->impl->shard_configure(rank, world); }
-int ekf_shard_get_view(ekf_filter* f, ekf_shard_view* out) { IMPL_OR_ARG(f); return f->impl->shard_view(out); }
-int ekf_shard_predict(ekf_filter* f, const void* t, const void* r, int vc) { IMPL_OR_ARG(f); return f->impl->shard_predict(t, r, vc); }
-int ekf_shard_innovation(ekf_filter* f, const void* dz, int M, int plane) { IMPL_OR_ARG(f); if (!dz) return EKF_ERR_ARG; return f->impl->shard_innovation(dz, M, plane); }
-int ekf_shard_factor_solve(ekf_filter* f) { IMPL_OR_ARG(f); return f->impl->shard_factor_solve(); }
-int ekf_shard_downdate(ekf_filter* f) { IMPL_OR_ARG(f); return f->impl->shard_downdate(); }
+int ekf_shard_configure(ekf_filter* f, int rank, int world, ekf_allgather_fn fn, void* ctx) {
+  IMPL_OR_ARG(f);
+  return f->impl->shard_configure(rank, world, fn, ctx);
+}
+int ekf_shard_get_info(ekf_filter* f, ekf_shard_info* out) { IMPL_OR_ARG(f); return f->impl->shard_info(out); }
+int ekf_shard_update(ekf_filter* f, const void* dz, const int* idx, int M, int plane) {
+  IMPL_OR_ARG(f);
+  return f->impl->shard_update(dz, idx, M, plane);
+}
+int ekf_shard_rebalance(ekf_filter* f) { IMPL_OR_ARG(f); return f->impl->shard_rebalance(); }
 
 void* ekf_device_mu(ekf_filter* f) { return f ? f->impl->dev_mu() : nullptr; }
 void* ekf_device_sigma(ekf_filter* f, int* ld) { return f ? f->impl->dev_sigma(ld) : nullptr; }

@@ -1,163 +1,301 @@
 """Row-panel sharding of the EKF step across the GPUs of one node, one process per GPU
 (include/ekf_monoslam.h "multi-GPU").
 
-Every rank holds the same feature list.  Rank g owns features [N g/G, N (g+1)/G), keeps the
-rows of Sigma of those features (all columns) plus a replica of the camera rows up to date, and
-a step is four local phases separated by all-gathers of DISJOINT panels (no reduction anywhere:
-on a fully connected xGMI node every peer pair moves its panel over its own link):
+Every rank holds the same filter (same calls in the same order everywhere) and OWNS a contiguous range of
+features: the rows of Sigma of those features (all columns) plus a replica of the camera rows stay valid on it; mu
+is replicated.  A step exchanges only DISJOINT panels, each by ONE all-gather of equal-sized staging slots (no
+reduction anywhere: on a fully connected xGMI node every peer pair moves its panel over its own link):
 
-    predict        -> all-gather h, Hc, Hf, flags     (per-feature slices, ~128 B / feature)
-    innovation     -> all-gather row panels of S      ((2M)^2 s bytes in total)
-    factor_solve   -> all-gather row panels of V      (n 2M s bytes in total)
-    downdate
+    predict                  -> per-feature records h | Hc | Hf | flags           ("reassemble H")
+    update: W rows, S rows   -> row panels of S                                   ("reassemble S")
+            per column chunk of the factorisation, beside the replicated Cholesky chain:
+            V_g = W_g Z_gg   -> own rows of V_g                                    (n x 2M scalars per step in all)
+            Sigma[own rows] -= V_g[own rows] V_g^T
+    convert2XYZ_ifLinearAll  -> linearity flags (one byte per feature)
+    re-balance               -> row panels of Sigma (only when a rank owns > 1.125 x the mean rows)
 
-`ShardedStep` only orchestrates; the arithmetic is in the backend it is given: `HipShardBackend`
-(the C ABI on a GPU, tensors are zero-copy views of the library's buffers) or, in the CPU tests,
-an oracle-backed stand-in with the same phase methods.  Collectives go through
-`torch.distributed` (backend "nccl" = RCCL on GPUs; "gloo" in the CPU tests).
+The orchestration lives in the library (csrc/ekf_capi.hip: shard_predict / shard_update / ...): it packs, calls the
+host's all-gather on its own stream, and unpacks.  This module supplies that callback over `torch.distributed`
+(backend "nccl" = RCCL on GPUs; "gloo" with host staging when several ranks share one GPU in the tests) and the
+multi-GPU leg of bench.py.  `ShardProtocol` is a numpy model of the same protocol over an oracle backend for the
+CPU tests (gloo, world 2 / 4): it poisons everything a rank does not own, so a protocol that reads a panel before
+the matching gather fails loudly.
 """
 from __future__ import annotations
 
 import ctypes as C
-import json
 import os
 import time
+import traceback
 
 import numpy as np
 
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+IMBALANCE_LIMIT = 1.125
 
-class ShardView(C.Structure):
-    """struct ekf_shard_view."""
-    _fields_ = [("rank", C.c_int), ("world", C.c_int), ("N", C.c_int), ("f_begin", C.c_int), ("f_end", C.c_int),
-                ("camera_dim", C.c_int), ("rows_per_rank", C.c_int),
-                ("m", C.c_int), ("m_pad", C.c_int), ("ldy", C.c_int),
-                ("d_h", C.c_void_p), ("d_Hc", C.c_void_p), ("d_Hf", C.c_void_p), ("d_flags", C.c_void_p),
-                ("d_S", C.c_void_p), ("d_V", C.c_void_p)]
+
+class ShardInfo(C.Structure):
+    """struct ekf_shard_info."""
+    _fields_ = [("rank", C.c_int), ("world", C.c_int), ("N", C.c_int), ("state_dim", C.c_int),
+                ("f_begin", C.c_int), ("f_end", C.c_int), ("row_begin", C.c_int), ("row_end", C.c_int),
+                ("max_rows_any_rank", C.c_int), ("rebalances", C.c_int)]
 
 
 class _DevArray:
     """Minimal __cuda_array_interface__ carrier: lets torch view library memory without a copy."""
 
-    def __init__(self, ptr, shape, typestr):
-        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False),
                                          "version": 2}
 
 
-def all_gather_rows(t, start, count, rank, world):
-    """In-place all-gather of `world` disjoint row blocks of the 2-D tensor `t`: rank r contributes
-    rows [start + r*count, start + (r+1)*count) and receives everybody else's."""
-    import torch
-    import torch.distributed as dist
-    if world == 1:
-        return
-    region = t[start:start + world * count]
-    own = t[start + rank * count:start + (rank + 1) * count]
-    backend = dist.get_backend()
-    if backend == "nccl" and region.is_cuda:
-        dist.all_gather_into_tensor(region.reshape(-1), own.reshape(-1))     # in place: own is a slice of region
-        return
-    # gloo (CPU tests, or several ranks sharing one GPU): stage through host copies
-    src = own.detach().cpu().contiguous()
-    parts = [torch.empty_like(src) for _ in range(world)]
-    dist.all_gather(parts, src)
-    for r, p in enumerate(parts):
-        if r != rank:
-            t[start + r * count:start + (r + 1) * count].copy_(p)
+class TorchAllGather:
+    """The ekf_allgather_fn of a rank: `world` equal slots, slot g = rank g's send buffer, on the library's stream.
 
+    nccl (RCCL): `all_gather_into_tensor(recv, send)` on plain, contiguous, separate send / receive staging buffers
+    -- the most ordinary form of the collective; torch enqueues it behind the current stream (the library's stream,
+    made current through `ExternalStream`) and makes that stream wait for it.
+    gloo (several ranks on one GPU, tests): the slots travel through host memory."""
 
-class HipShardBackend:
-    """Phase methods of one rank on its GPU (the ekf_shard_* entry points)."""
-
-    def __init__(self, flt, rank, world, stream=None):
+    def __init__(self, world, rank, device_index=0):
         import torch
-        self.flt = flt
-        self.lib = flt._lib
-        self.rank, self.world = rank, world
-        self._check(self.lib.ekf_shard_configure(flt._h, rank, world))
-        # the phases and the collectives must be ordered on ONE stream: run the library on torch's
-        # current stream (the stream RCCL synchronises with) unless the caller names another one
-        flt.set_stream(torch.cuda.current_stream().cuda_stream if stream is None else stream)
-        self.torch = torch
-        self.dtype = torch.float32 if flt.dtype == np.float32 else torch.float64
-        self.typestr = "<f4" if flt.dtype == np.float32 else "<f8"
-        self._views = None
-        self.refresh_view()
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world, self.rank, self.device_index = world, rank, device_index
+        self.backend = dist.get_backend() if world > 1 else "none"
+        self._views = {}
+        self._streams = {}
+        self.calls = 0
+        self.bytes_sent = 0
+        self.seconds = 0.0                      # host time inside the callback (gloo: the whole exchange)
+        self.error = None
+        self.c_callback = ALLGATHER_FN(self._call)
 
-    def _check(self, rc):
-        self.flt._check(rc)
-
-    def refresh_view(self):
-        v = ShardView()
-        self._check(self.lib.ekf_shard_get_view(self.flt._h, C.byref(v)))
-        self.view = v
-        self.N, self.f0, self.f1 = v.N, v.f_begin, v.f_end
-        self.camera_dim, self.rows_per_rank, self.ldy = v.camera_dim, v.rows_per_rank, v.ldy
+    def _view(self, ptr, nbytes):
+        key = (ptr, nbytes)
+        v = self._views.get(key)
+        if v is None:
+            if len(self._views) > 64:
+                self._views.clear()
+            v = self.torch.as_tensor(_DevArray(ptr, nbytes), device=f"cuda:{self.device_index}")
+            self._views[key] = v
         return v
 
-    def tensors(self):
-        """Zero-copy torch views: h (N,2), Hc (N,14), Hf (N,12), flags (N,1), S (2N,ldy), V (n,ldy)."""
-        if self._views is None:
-            t, v = self.torch, self.view
-            n = self.camera_dim + 6 * self.N
+    def _call(self, ctx, d_send, d_recv, nbytes, stream):
+        try:
+            t0 = time.perf_counter()
+            torch, dist = self.torch, self.dist
+            send = self._view(d_send, nbytes)
+            recv = self._view(d_recv, nbytes * self.world)
+            st = self._streams.get(stream)
+            if st is None:
+                st = torch.cuda.ExternalStream(stream, device=f"cuda:{self.device_index}") if stream else \
+                    torch.cuda.default_stream(self.device_index)
+                self._streams[stream] = st
+            with torch.cuda.stream(st):
+                if self.backend == "nccl":
+                    dist.all_gather_into_tensor(recv, send)
+                else:
+                    host = send.cpu()
+                    parts = [torch.empty_like(host) for _ in range(self.world)]
+                    dist.all_gather(parts, host)
+                    recv.copy_(torch.cat(parts))
+            self.calls += 1
+            self.bytes_sent += int(nbytes)
+            self.seconds += time.perf_counter() - t0
+            return 0
+        except Exception as e:                  # never let an exception unwind through the C frames
+            self.error = e
+            traceback.print_exc()
+            return 1
 
-            def view(ptr, shape, ts):
-                return t.as_tensor(_DevArray(ptr, shape, ts), device="cuda")
-            self._views = {
-                "h": view(v.d_h, (self.N, 2), self.typestr), "Hc": view(v.d_Hc, (self.N, 14), self.typestr),
-                "Hf": view(v.d_Hf, (self.N, 12), self.typestr), "flags": view(v.d_flags, (self.N, 1), "|u1"),
-                "S": view(v.d_S, (2 * self.N, self.ldy), self.typestr), "V": view(v.d_V, (n, self.ldy), self.typestr)}
-        return self._views
 
+def configure(flt, rank, world, device_index=0):
+    """Switch a VSlamFilter (every rank built it by the same calls) to sharded operation over torch.distributed."""
+    ag = TorchAllGather(world, rank, device_index) if world > 1 else None
+    flt._allgather = ag                          # keeps the ctypes callback alive as long as the filter
+    flt._check(flt._lib.ekf_shard_configure(flt._h, int(rank), int(world),
+                                            ag.c_callback if ag else C.cast(None, ALLGATHER_FN), None))
+    return ag
+
+
+def shard_info(flt):
+    info = ShardInfo()
+    flt._check(flt._lib.ekf_shard_get_info(flt._h, C.byref(info)))
+    return info
+
+
+def shard_update(flt, d_z_ptr, indices, plane=False):
+    idx = np.ascontiguousarray(indices, np.int32)
+    flt._check(flt._lib.ekf_shard_update(flt._h, C.c_void_p(d_z_ptr), idx.ctypes.data_as(C.c_void_p), idx.size,
+                                         int(bool(plane))))
+
+
+def rebalance(flt):
+    flt._check(flt._lib.ekf_shard_rebalance(flt._h))
+
+
+# ---------------------------------------------------------------------------------------------
+# numpy model of the protocol (CPU tests, gloo): same ownership rules, same exchanges, padded equal slots
+# ---------------------------------------------------------------------------------------------
+def partition_by_rows(pos, n, camera_dim, world):
+    """Feature boundaries (world + 1 entries) that balance the state ROWS: Filter::partition_by_rows."""
+    N = len(pos)
+    fb = [N] * (world + 1)
+    fb[0] = 0
+    rows = n - camera_dim
+    f = 0
+    for g in range(1, world):
+        target = rows * g // world
+        while f < N and pos[f] - camera_dim < target:
+            f += 1
+        fb[g] = f
+    return fb
+
+
+def _all_gather_padded(own, counts, rank, world):
+    """All-gather of per-rank arrays with different leading sizes through equal, padded slots (what the library's
+    staging buffers are): returns the list of every rank's array."""
+    import torch
+    import torch.distributed as dist
+    mx = max(counts)
+    tail = own.shape[1:]
+    slot = np.zeros((mx,) + tail, own.dtype)
+    slot[:own.shape[0]] = own
+    if world == 1:
+        return [own]
+    send = torch.from_numpy(slot)
+    parts = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(parts, send)
+    return [parts[g].numpy()[:counts[g]] for g in range(world)]
+
+
+class ShardProtocol:
+    """The sharded step over a backend that does the arithmetic of ONE rank on numpy arrays (tests/sharded_common.py:
+    the structured oracle with everything a rank does not own poisoned with NaN)."""
+
+    def __init__(self, backend, rank, world):
+        self.b, self.rank, self.world = backend, rank, world
+        self.fb = partition_by_rows(backend.positions(), backend.n, backend.camera_dim, world)
+        self.rebalances = 0
+        backend.set_owner(self.own_features(), self.own_rows())
+
+    # -- ownership ------------------------------------------------------------------------------
+    def own_features(self):
+        return range(self.fb[self.rank], self.fb[self.rank + 1])
+
+    def _row_of(self, f):
+        pos = self.b.positions()
+        return pos[f] if f < len(pos) else self.b.n
+
+    def rows_of_rank(self, g):
+        return range(self._row_of(self.fb[g]), self._row_of(self.fb[g + 1]))
+
+    def own_rows(self):
+        return self.rows_of_rank(self.rank)
+
+    def _retag(self):
+        self.b.set_owner(self.own_features(), self.own_rows())
+
+    def needs_rebalance(self):
+        if self.world == 1 or not len(self.b.positions()):
+            return False
+        mx = max(len(self.rows_of_rank(g)) for g in range(self.world))
+        mean = (self.b.n - self.b.camera_dim) / self.world
+        return mx > IMBALANCE_LIMIT * mean + 6.0
+
+    # -- resize: every rank runs the operation, ownership follows (Filter::shard_after_*) -------------
+    def add_feature(self, u, v):
+        ok = self.b.add_feature(u, v)
+        if ok:
+            self.fb[self.world] = len(self.b.positions())
+            self._retag()
+        return ok
+
+    def remove_features(self, indices):
+        N = len(self.b.positions())
+        rm = np.zeros(N, bool)
+        rm[list(indices)] = True
+        kept_before = np.concatenate([[0], np.cumsum(~rm)])
+        self.b.remove_features(sorted(indices))
+        self.fb = [int(kept_before[min(f, N)]) for f in self.fb]
+        self._retag()
+
+    def convert_all(self):
+        own = np.array(list(self.own_features()), dtype=np.int64)
+        flags = self.b.linearity_flags(own).astype(np.uint8)
+        counts = [self.fb[g + 1] - self.fb[g] for g in range(self.world)]
+        parts = _all_gather_padded(flags.reshape(-1, 1), counts, self.rank, self.world)
+        allf = np.concatenate([p.reshape(-1) for p in parts]).astype(bool)
+        cnt = self.b.convert(np.nonzero(allf)[0].tolist())
+        self._retag()
+        return cnt
+
+    def rebalance(self):
+        counts = [len(self.rows_of_rank(g)) for g in range(self.world)]
+        rows = self.b.sigma_rows(self.own_rows())
+        parts = _all_gather_padded(rows, counts, self.rank, self.world)
+        for g in range(self.world):
+            if g != self.rank:
+                self.b.set_sigma_rows(self.rows_of_rank(g), parts[g])
+        self.fb = partition_by_rows(self.b.positions(), self.b.n, self.b.camera_dim, self.world)
+        self.rebalances += 1
+        self._retag()
+
+    # -- the step -----------------------------------------------------------------------------------
     def predict(self):
-        self._check(self.lib.ekf_shard_predict(self.flt._h, None, None, 0))
-
-    def innovation(self, d_z_ptr, M):
-        self._check(self.lib.ekf_shard_innovation(self.flt._h, C.c_void_p(d_z_ptr), int(M), 0))
-
-    def factor_solve(self):
-        self._check(self.lib.ekf_shard_factor_solve(self.flt._h))
-
-    def downdate(self):
-        self._check(self.lib.ekf_shard_downdate(self.flt._h))
-
-
-class ShardedStep:
-    """One EKF step (predict + full-batch update over M = N features) across the ranks."""
-
-    def __init__(self, backend):
-        self.b = backend
-        self.rank, self.world = backend.rank, backend.world
-        self.comm_s = 0.0
-
-    def _gather(self, what, t, start, count):
-        """One all-gather; with `self.timing` set (a dict of event-pair lists) it is bracketed by events on
-        the current stream, the stream the phases and RCCL are ordered on."""
-        if self.timing is None:
-            all_gather_rows(t, start, count, self.rank, self.world)
-            return
-        import torch
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        all_gather_rows(t, start, count, self.rank, self.world)
-        e1.record()
-        self.timing.setdefault(what, []).append((e0, e1))
-
-    timing = None
-
-    def step(self, z):
-        """z: backend-specific handle of this frame's 2N measurements (device pointer for the HIP
-        backend, array for the CPU stand-in)."""
+        if self.needs_rebalance():
+            self.rebalance()
         b = self.b
-        nf = b.f1 - b.f0
-        b.predict()
-        ts = b.tensors()
-        for name in ("h", "Hc", "Hf", "flags"):                     # reassemble H
-            self._gather("H", ts[name], 0, nf)
-        b.innovation(z, b.N)
-        self._gather("S", ts["S"], 0, 2 * nf)                        # reassemble S
-        b.factor_solve()
-        self._gather("V", ts["V"], b.camera_dim, b.rows_per_rank)
-        b.downdate()
+        b.predict_camera_and_strips()
+        own = list(self.own_features())
+        rec = b.measure(own)                                  # (count, 29): h | Hc | Hf | flag
+        counts = [self.fb[g + 1] - self.fb[g] for g in range(self.world)]
+        parts = _all_gather_padded(rec, counts, self.rank, self.world)
+        for g in range(self.world):
+            if g != self.rank:
+                b.set_records(range(self.fb[g], self.fb[g + 1]), parts[g])
+
+    def update(self, z, indices, plane=False, chunks=2):
+        b = self.b
+        indices = list(indices)
+        M = len(indices)
+        if M == 0 and not plane:
+            return
+        # list positions of every rank's measured features (ascending list, contiguous ownership)
+        kr = []
+        k = 0
+        for g in range(self.world):
+            while k < M and indices[k] < self.fb[g]:
+                k += 1
+            e = k
+            while e < M and indices[e] < self.fb[g + 1]:
+                e += 1
+            kr.append((k, e))
+            k = e
+        k0, k1 = kr[self.rank]
+        b.begin_update(z, indices, plane)                     # nu (replicated), W rows {camera, own}
+        S_own = b.innovation_rows(k0, k1)                     # rows 2 k0 .. 2 k1 of S
+        parts = _all_gather_padded(S_own, [2 * (e - s) for s, e in kr], self.rank, self.world)
+        for g in range(self.world):
+            if g != self.rank:
+                b.set_S_rows(2 * kr[g][0], parts[g])
+        b.factor()                                            # replicated chain (incl. the plane / tail rows)
+        m = b.m
+        ends = sorted(set([m * (c + 1) // chunks for c in range(chunks)]))
+        c0 = 0
+        row_counts = [len(self.rows_of_rank(g)) for g in range(self.world)]
+        for c1 in ends:
+            if c1 == c0:
+                continue
+            V_own = b.solve_chunk(c0, c1)                     # own rows of V[:, c0:c1] (+ camera rows, + y, replicated)
+            parts = _all_gather_padded(V_own, row_counts, self.rank, self.world)
+            for g in range(self.world):
+                if g != self.rank:
+                    b.set_V_rows(self.rows_of_rank(g), c0, c1, parts[g])
+            b.downdate_chunk(c0, c1)                          # Sigma[{camera, own}, :] -= V_g[rows] V_g^T
+            c0 = c1
+        b.finish_update()                                     # mu += V y, quaternion normalisation
 
 
 # ---------------------------------------------------------------------------------------------
@@ -166,21 +304,15 @@ class ShardedStep:
 def bench(pkg, cfg, n_feat, px0, z, args, rank, world, dev):
     import torch
     import torch.distributed as dist
-    if n_feat % world != 0:
-        raise SystemExit(f"--features {n_feat} must be divisible by the number of GPUs ({world})")
+    import bench as _bench
     # a map runs `seg` frames (bench.segment_frames: the fp32 covariance of a map whose features are ALL measured in
     # EVERY frame stops being positive after a few hundred frames); longer runs continue on a map started afresh
     # from the stream's current pixels -- all maps are built before the clock starts
-    import bench as _bench
     seg = _bench.segment_frames(n_feat)
     frames = args.warmup + args.steps
     nseg = max(1, -(-frames // seg))
     if nseg > 64:
         raise SystemExit(f"--steps {frames}: more than 64 map restarts of {seg} frames at N = {n_feat}; use fewer steps")
-    # everything of the step -- library phases and collectives -- is ordered on ONE non-default stream: on the legacy
-    # default stream every kernel would synchronise with the library's internal second stream
-    side = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(side)
     maps = []
     for sgi in range(nseg):
         f_ = pkg.VSlamFilter(cfg, capacity_features=n_feat, dtype=np.float32, device=dev.index)
@@ -189,24 +321,32 @@ def bench(pkg, cfg, n_feat, px0, z, args, rank, world, dev):
             if f_.addFeature((u, v)) != 1:
                 raise RuntimeError("synthetic pixel rejected by addFeature")
         f_.synchronize()
-        b_ = HipShardBackend(f_, rank, world, stream=torch.cuda.current_stream().cuda_stream)
-        maps.append((f_, ShardedStep(b_)))
-    flt, stepper = maps[0]
+        configure(f_, rank, world, dev.index)
+        maps.append(f_)
+    flt = maps[0]
     d_z = torch.from_numpy(z.reshape(z.shape[0], -1)).to(dev).contiguous()
+    idx = np.arange(n_feat, dtype=np.int32)
     bpf = 2 * n_feat * 4
     n = flt.stateDim()
 
     def run(first, count):
         for f in range(first, first + count):
-            maps[min(f // seg, nseg - 1)][1].step(d_z.data_ptr() + f * bpf)
+            m_ = maps[min(f // seg, nseg - 1)]
+            m_.predict()
+            shard_update(m_, d_z.data_ptr() + f * bpf, idx)
+
+    def sync_all():
+        for m_ in maps:
+            m_.synchronize()
+        torch.cuda.synchronize()
 
     run(0, args.warmup)
-    torch.cuda.synchronize()
+    sync_all()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(args.warmup, args.steps)
-    torch.cuda.synchronize()
+    sync_all()
     dist.barrier()
     torch.cuda.synchronize()
     elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
@@ -214,34 +354,32 @@ def bench(pkg, cfg, n_feat, px0, z, args, rank, world, dev):
     dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
 
-    mu = maps[min((frames - 1) // seg, nseg - 1)][0].getFullState()
+    mu = maps[min((frames - 1) // seg, nseg - 1)].getFullState()
     sane = bool(np.all(np.isfinite(mu)) and abs(np.linalg.norm(mu[3:7]) - 1) < 1e-4)
-    # per-phase share of one step on this rank (HIP events around every kernel, separate short pass)
+    # per-phase share of one step on this rank (HIP events around every kernel and every exchange, separate short pass)
     flt.set_option(2, 2)
     flt.profile_reset()
-    stepper.timing = {}
-    run(args.warmup, min(5, args.steps))
-    torch.cuda.synchronize()
-    prof = flt.profile()
-    flt.set_option(2, 0)
     k = min(5, args.steps)
-    gather_ms = {what: round(sum(a.elapsed_time(b) for a, b in pairs) / k, 4) for what, pairs in stepper.timing.items()}
-    stepper.timing = None
+    run(args.warmup, k)
+    sync_all()
+    prof = flt.profile()
+    work = flt.profile_work()
+    flt.set_option(2, 0)
     phase = {name: round(ms / k, 4) for name, (ms, cnt) in prof.items()}
-    shard_ms = sum(phase.get(x, 0.0) for x in ("measure", "sigma_ht", "innovation_cov"))
-    # dominant kernel of a rank: its row panel of the downdate, (n / G) x n x m multiply-adds, every column
-    # (a panel cannot use the symmetry), timed with HIP events on the library's stream in the pass above
+    gather_ms = {name[len("allgather_"):].upper(): v for name, v in phase.items() if name.startswith("allgather_")}
+    shard_ms = sum(phase.get(x, 0.0) for x in ("measure", "innovation", "sigma_ht", "innovation_cov"))
+    # dominant kernel of a rank: its row panel of the downdate, rows x n x m multiply-adds, every column
+    # (a row panel cannot use the symmetry), timed with HIP events on the library's streams in the pass above
     dd_ms, dd_cnt = prof.get("downdate_syrk", (0.0, 0))
     roofline = None
     if dd_cnt:
-        launches_per_step = dd_cnt / k
-        rows = n / world
-        flop = 2.0 * rows * n * (2 * n_feat) / max(1.0, round(launches_per_step))
+        flop = work.get("downdate_syrk", 0.0) / dd_cnt
         ach = flop / (dd_ms / dd_cnt * 1e-3) / 1e12
-        roofline = {"kernel": "downdate row panel (k_gemm_nt_mfma, f32 MFMA 32x32x2), rank 0", "bound": "mfma",
+        roofline = {"kernel": "downdate row panel (k_gemm_mfma, f32 MFMA 32x32x2), rank 0", "bound": "mfma",
                     "achieved": round(ach, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4),
                     "traffic": None, "avg_launch_ms": round(dd_ms / dd_cnt, 4),
-                    "algorithmic_flop_per_launch": flop, "launches_per_step": launches_per_step}
+                    "algorithmic_flop_per_launch": flop, "launches_per_step": dd_cnt / k}
+    info = shard_info(flt)
     result = {
         "metric": "EKF updates/sec at N features (state dim 14+6N)",
         "value": round(args.steps / elapsed, 2), "unit": "updates/s",
@@ -251,14 +389,16 @@ def bench(pkg, cfg, n_feat, px0, z, args, rank, world, dev):
         "config": {"workload": f"N={n_feat} inverse-depth features, n={n}, M=N measured per frame, fp32, "
                                f"row-panel shard over {world} GPUs (BASELINE configs[3])",
                    "features": n_feat, "state_dim": n, "measured_per_frame": n_feat,
-                   "parallelism": f"row-panel shard x{world}: all-gather H, S, V over RCCL",
+                   "parallelism": f"row-panel shard x{world}: all-gather H, S, V over RCCL, chunk-pipelined beside the "
+                                  "replicated Cholesky chain",
                    "frames_per_map": seg, "maps": nseg},
         "run_sane": sane,
+        "rank0_rows": [info.row_begin, info.row_end],
         "per_rank_kernel_ms": phase,
         "jacobian_innovation_shard_ms": round(shard_ms, 4),
         "allgather_ms_per_step": gather_ms,
         "roofline": roofline, "cpu_baseline": None,
     }
-    for f_, _ in maps:
+    for f_ in maps:
         f_.close()
     return result

@@ -298,6 +298,10 @@ class VSlamFilter:
         mu = np.ascontiguousarray(mu, self.dtype)
         self._check(self._lib.ekf_set_state(self._h, self._ptr(mu), 0, mu.size))
 
+    def setStateSegment(self, offset: int, values):
+        v = np.ascontiguousarray(values, self.dtype).reshape(-1)
+        self._check(self._lib.ekf_set_state(self._h, self._ptr(v), int(offset), v.size))
+
     def getSigma(self):
         """Sigma[0:STATE_DIM, 0:STATE_DIM] (vR.cpp:131-133)."""
         return self.getSigmaBlock(0, 0, self.camera_dim, self.camera_dim)

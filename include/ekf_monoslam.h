@@ -26,11 +26,13 @@
 #ifndef EKF_MONOSLAM_H_
 #define EKF_MONOSLAM_H_
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define EKF_ABI_VERSION 1
+#define EKF_ABI_VERSION 2
 
 typedef struct ekf_filter ekf_filter;
 
@@ -263,36 +265,52 @@ int ekf_profile_reset(ekf_filter* f);
  * carries the W update of its chunk). */
 int ekf_profile_work(ekf_filter* f, int kernel_id, double* flop);
 
-/* ---- multi-GPU: row-panel sharding, one process per GPU --------------------
- * Every rank holds the same feature list; rank g owns features [N g/G, N (g+1)/G) and keeps the
- * rows of Sigma of those features (all columns) plus a replica of the camera rows up to date.
- * A step is four local phases separated by all-gathers of disjoint panels, which the host does
- * with RCCL (torch.distributed) on the buffers of `ekf_shard_view`:
- *   ekf_shard_predict      camera step + strips; h / H / flags of the OWN features
- *       -> all-gather h, Hc, Hf, flags (per-feature slices)                  "reassemble H"
- *   ekf_shard_innovation   nu; W = Sigma H^T rows {camera, own}; S rows of the own features
- *       -> all-gather the row panels of S                                     "reassemble S"
- *   ekf_shard_factor_solve Cholesky chain of S (replicated), V = W L^-T rows {camera, own}, y
- *       -> all-gather the row panels of V
- *   ekf_shard_downdate     mu += V y; Sigma[own rows, :] -= V[own rows] V^T; normalisation
- * Round-1 limits: inverse-depth features only, N divisible by the world size, every feature
- * measured (M = N, identity index list) -- anything else returns EKF_ERR_UNSUPPORTED. */
-typedef struct ekf_shard_view {
-  int rank, world, N, f_begin, f_end;     /* own feature range                                  */
-  int camera_dim, rows_per_rank;          /* own Sigma / W / V rows: camera_dim + rank * rows_per_rank ... */
-  int m, m_pad, ldy;                      /* rows of S (2M (+3)), padded, leading dimension      */
-  void* d_h;  void* d_Hc;  void* d_Hf;    /* per-feature arrays: 2, 14, 12 scalars per feature   */
-  unsigned char* d_flags;                 /* 1 byte per feature                                  */
-  void* d_S;                              /* S, row-major, ldy per row; own rows = 2*f_begin ... */
-  void* d_V;                              /* V, row-major, ldy per row                           */
-} ekf_shard_view;
+/* ---- multi-GPU: row-panel sharding, one process per GPU ----------------------------------------
+ * Every rank holds the same filter (same calls in the same order on every rank: add / remove / convert / predict /
+ * update) and OWNS a contiguous range of features: it keeps valid the rows of Sigma of those features (all columns)
+ * plus a replica of the camera rows; mu is replicated.  One sharded step:
+ *   predict   camera step + strips; h / H / flags of the OWN features
+ *       -> all-gather of the per-feature records (32 scalars per feature)             "reassemble H"
+ *   update    nu; W = Sigma H^T rows {camera, own}; rows of S of the own MEASURED features
+ *       -> all-gather of the row panels of S                                           "reassemble S"
+ *             Cholesky chain of S in column chunks (replicated); per chunk g, beside the chain on a second stream:
+ *             V_g = W_g Z_gg and the right-looking W update for rows {camera tile, own panel}
+ *       -> all-gather of the own rows of V_g                                           (n x 2M scalars per step in all)
+ *             Sigma[own rows, :] -= V_g[own rows] V_g^T (+ the replicated camera tile); then mu += V y, normalisation.
+ * Any measured subset (strictly ascending list, M <= N), inverse-depth and XYZ features, the plane rows and any N
+ * (ranks may own different numbers of features, or none) are supported.  add_feature appends to the LAST rank's
+ * range, remove / convert compact every rank's copy alike; when a rank owns more than 1.125 x the mean number of
+ * rows the next predict re-partitions (ekf_shard_rebalance: all-gather of the row panels of Sigma, after which every
+ * row is valid on every rank, then a fresh row-balanced partition).
+ *
+ * The library does no communication itself: every exchange is ONE call of the host's all-gather on device staging
+ * buffers -- `world` equal slots, slot g = the `bytes_per_rank` bytes rank g passed as d_send, delivered to every
+ * rank, enqueued on `hip_stream` (the library packs before and unpacks after on that same stream).  With
+ * torch.distributed this is `all_gather_into_tensor` (backend "nccl" = RCCL over xGMI; sharded.py); a C++ node
+ * passes a function that calls ncclAllGather(d_send, d_recv, bytes_per_rank, ncclChar, comm, stream).  Every rank
+ * makes the same sequence of calls with the same sizes.  Return 0 on success. */
+typedef int (*ekf_allgather_fn)(void* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank, void* hip_stream);
 
-int ekf_shard_configure(ekf_filter* f, int rank, int world);
-int ekf_shard_get_view(ekf_filter* f, ekf_shard_view* out);
-int ekf_shard_predict(ekf_filter* f, const void* t_ctl, const void* r_ctl, int vcontrol);
-int ekf_shard_innovation(ekf_filter* f, const void* d_z, int M, int plane_constraint);
-int ekf_shard_factor_solve(ekf_filter* f);
-int ekf_shard_downdate(ekf_filter* f);
+typedef struct ekf_shard_info {
+  int rank, world, N, state_dim;
+  int f_begin, f_end;                     /* own feature range                                             */
+  int row_begin, row_end;                 /* own state rows                                                 */
+  int max_rows_any_rank;                  /* the largest panel (imbalance = this x world / (n - camera_dim)) */
+  int rebalances;                         /* re-partitions since ekf_shard_configure                        */
+} ekf_shard_info;
+
+/* Switches the filter to sharded operation.  Call it at a point where every rank holds the same, fully valid
+ * filter (e.g. right after the identical construction of the map).  From then on ekf_predict, ekf_update (host
+ * z / indices), ekf_add_feature, ekf_remove_feature(s) and ekf_convert_xyz_if_linear(_all) run the sharded step;
+ * getters of Sigma are valid for the camera rows and the own rows only (ekf_shard_rebalance makes all rows valid);
+ * ekf_update_device, ekf_ransac_1point, ekf_rescue_high_innovation, ekf_innovation_covariance and the image side
+ * are not available on a sharded filter.  world = 1 needs no callback. */
+int ekf_shard_configure(ekf_filter* f, int rank, int world, ekf_allgather_fn allgather, void* ctx);
+int ekf_shard_get_info(ekf_filter* f, ekf_shard_info* out);
+/* ekf_update with z (2 M scalars) resident in device memory and the measured list on the host. */
+int ekf_shard_update(ekf_filter* f, const void* d_z, const int* indices, int M, int plane_constraint);
+/* All-gather of the row panels of Sigma + fresh partition (also done automatically, see above). */
+int ekf_shard_rebalance(ekf_filter* f);
 
 /* Raw device pointers for zero-copy plumbing (torch / RCCL): mu, the live Sigma buffer,
  * and its leading dimension (device storage is row-major, ld elements per row). */

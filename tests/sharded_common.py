@@ -1,103 +1,185 @@
-"""Test-only stand-in for the HIP shard backend: the same four phases on numpy row panels.
-It keeps ONLY the rows a rank owns (its features + the camera rows) valid and poisons every
-other row of its Sigma / W / V copies with NaN after each phase, so an orchestration that reads a
-panel before the matching all-gather fails loudly."""
+"""Test-only backend of `sharded.ShardProtocol`: the arithmetic of ONE rank on the structured oracle.
+It keeps ONLY what the rank owns valid -- the rows of Sigma of its features plus the camera rows, the W / V rows it
+computed, the per-feature records it measured -- and poisons everything else with NaN after every operation, so a
+protocol that reads a panel before the matching all-gather (or forgets one) produces NaN and fails loudly."""
 import numpy as np
-import torch
 
 import ekf_oracle as o
 
 
 class OracleShardBackend:
-    def __init__(self, filt: o.StructuredFilter, rank, world):
+    def __init__(self, filt: o.StructuredFilter):
         self.f = filt
-        self.rank, self.world = rank, world
-        self.N = filt.num_features()
-        assert self.N % world == 0
-        nf = self.N // world
-        self.f0, self.f1 = rank * nf, (rank + 1) * nf
         self.camera_dim = filt.camera_dim
-        self.rows_per_rank = 6 * nf
-        self.r0 = self.camera_dim + 6 * self.f0
-        self.r1 = self.r0 + self.rows_per_rank
-        T = filt.T
-        n = filt.n
-        tdt = torch.float64 if T == np.float64 else torch.float32
-        self._t = {"h": torch.zeros((self.N, 2), dtype=tdt), "Hc": torch.zeros((self.N, 14), dtype=tdt),
-                   "Hf": torch.zeros((self.N, 12), dtype=tdt), "flags": torch.zeros((self.N, 1), dtype=torch.uint8),
-                   "S": torch.zeros((2 * self.N, 2 * self.N), dtype=tdt), "V": torch.zeros((n, 2 * self.N), dtype=tdt)}
-        self.W = np.full((n, 2 * self.N), np.nan, dtype=T)
+        self.own_f = range(0)
+        self.own_r = range(0)
+
+    # -- layout / ownership -----------------------------------------------------------------------
+    @property
+    def n(self):
+        return self.f.n
+
+    def positions(self):
+        return [ft.position_in_state for ft in self.f.features]
+
+    def set_owner(self, features, rows):
+        self.own_f, self.own_r = features, rows
         self._poison()
 
-    def tensors(self):
-        return self._t
-
-    def own_rows(self):
-        return np.r_[0:self.camera_dim, self.r0:self.r1]
+    def valid_rows(self):
+        return np.r_[0:self.camera_dim, self.own_r.start:self.own_r.stop].astype(np.int64)
 
     def _poison(self):
         mask = np.ones(self.f.n, bool)
-        mask[self.own_rows()] = False
+        mask[self.valid_rows()] = False
         self.f.Sigma[mask, :] = np.nan
 
-    def predict(self):
+    # -- resize (every rank runs these) -------------------------------------------------------------
+    def add_feature(self, u, v):
+        return self.f.add_feature(u, v)
+
+    def remove_features(self, indices):
+        for i in reversed(indices):                      # descending, vR.cpp:1296-1299
+            self.f.remove_feature(i)
+
+    def linearity_flags(self, own):
+        f = self.f
+        out = np.zeros(len(own), bool)
+        for j, i in enumerate(own):
+            ft = f.features[i]
+            if ft.coding == o.INV:
+                p = ft.position_in_state
+                out[j] = f.inverse_depth_to_xyz_world(f.mu[p:p + 6], 2, p)[2]
+        return out
+
+    def convert(self, which):
+        """Convert the listed features in index order, as convert2XYZ_ifLinearAll walks them (vR.cpp:776-780): the
+        decision was taken by the owners; the Jacobian needs mu only (replicated)."""
+        f = self.f
+        T = f.T
+        for i in which:
+            ft = f.features[i]
+            pos = ft.position_in_state
+            y, J_y, _ = f.inverse_depth_to_xyz_world(f.mu[pos:pos + 6], 1)
+            f._convert_covariance(pos, J_y)
+            f.mu = np.concatenate([f.mu[:pos], y.astype(T), f.mu[pos + 6:]])
+            ft.coding = o.XYZ
+            for g in f.features[i + 1:]:
+                g.position_in_state -= 3
+        return len(which)
+
+    def sigma_rows(self, rows):
+        return self.f.Sigma[rows.start:rows.stop, :].copy()
+
+    def set_sigma_rows(self, rows, arr):
+        self.f.Sigma[rows.start:rows.stop, :] = arr
+
+    # -- predict ------------------------------------------------------------------------------------
+    def predict_camera_and_strips(self):
         f = self.f
         Ft, Q = f._motion((0, 0, 0), (0, 0, 0), False)
         f.predict_covariance(Ft, Q)
         f.mu[0:13] = o.predict_state(f.mu[0:13], (0, 0, 0), (0, 0, 0), f.dT, f.T)
-        t = self._t
-        for name in ("h", "Hc", "Hf"):
-            t[name].fill_(float("nan"))
-        for i in range(self.f0, self.f1):
-            hi, Hc, Hf, vis, rem = f.measure_feature(f.features[i])
-            t["h"][i] = torch.from_numpy(hi)
-            t["Hc"][i] = torch.from_numpy(Hc.reshape(-1))
-            t["Hf"][i] = torch.from_numpy(Hf.reshape(-1))
-            t["flags"][i, 0] = int(vis) | (int(rem) << 1)
+        for ft in f.features:                            # nothing of the per-feature records survives a predict
+            ft.h = ft.Hc = ft.Hf = None
+            ft.is_in_innovation = False
 
-    def innovation(self, z, M):
+    def measure(self, own):
+        f = self.f
+        rec = np.zeros((len(own), 29), f.T)
+        for j, i in enumerate(own):
+            ft = f.features[i]
+            hi, Hc, Hf, vis, rem = o.DenseFilter.measure_feature(f, ft)
+            ft.h, ft.Hc, ft.Hf, ft.is_in_innovation = hi, Hc, Hf, vis
+            if rem:
+                ft.remove_flag = True
+            rec[j, 0:2] = hi
+            rec[j, 2:16] = Hc.reshape(-1)
+            rec[j, 16:16 + ft.size], rec[j, 22:22 + ft.size] = Hf[0], Hf[1]   # 2 x 6 block, an XYZ feature fills 2 x 3
+            rec[j, 28] = int(vis) | (int(rem) << 1)
+        return rec
+
+    def set_records(self, frange, rec):
+        f = self.f
+        for j, i in enumerate(frange):
+            ft = f.features[i]
+            s = ft.size
+            ft.h = rec[j, 0:2].copy()
+            ft.Hc = rec[j, 2:16].reshape(2, 7).copy()
+            ft.Hf = np.stack([rec[j, 16:16 + s], rec[j, 22:22 + s]]).copy()
+            fl = int(rec[j, 28])
+            ft.is_in_innovation = bool(fl & 1)
+            if fl & 2:
+                ft.remove_flag = True
+
+    def visible_indices(self):
+        return self.f.visible_indices()
+
+    # -- update -------------------------------------------------------------------------------------
+    def begin_update(self, z, indices, plane):
         f = self.f
         T = f.T
-        t = self._t
-        h = t["h"].numpy().astype(T)
-        Hc = t["Hc"].numpy().astype(T).reshape(self.N, 2, 7)
-        Hf = t["Hf"].numpy().astype(T).reshape(self.N, 2, 6)
-        assert np.all(np.isfinite(h)) and np.all(np.isfinite(Hc))       # gathered before use
-        self.nu = np.asarray(z, T).reshape(-1) - h.reshape(-1)
-        rows = self.own_rows()
-        self.W[:] = np.nan
-        for k, ft in enumerate(f.features):
-            p = ft.position_in_state
-            self.W[rows, 2 * k:2 * k + 2] = f.Sigma[rows, 0:7] @ Hc[k].T + f.Sigma[rows, p:p + 6] @ Hf[k].T
-        S = t["S"]
-        S.fill_(float("nan"))
-        for k in range(self.f0, self.f1):
-            p = f.features[k].position_in_state
-            blk = Hc[k] @ self.W[0:7, :] + Hf[k] @ self.W[p:p + 6, :]
-            blk[0, 2 * k] += T(f.sigma_pixel_2)
-            blk[1, 2 * k + 1] += T(f.sigma_pixel_2)
-            S[2 * k:2 * k + 2] = torch.from_numpy(blk)
+        for i in indices:
+            assert f.features[i].h is not None and np.all(np.isfinite(f.features[i].Hc))      # gathered before use
+        self.indices, self.plane = list(indices), bool(plane)
+        M = len(indices)
+        self.m = 2 * M + (3 if plane else 0)
+        h = f.stacked_h(self.indices)
+        z = np.asarray(z, T).reshape(-1)
+        if plane:
+            h = np.concatenate([h, np.array([f.mu[1], f.mu[4], f.mu[6]], T)])
+            z = np.concatenate([z, np.zeros(3, T)])
+        self.nu = z - h
+        W = f.sigma_Ht(self.indices, plane)               # rows of foreign features are NaN (their Sigma rows are)
+        keep = np.zeros(f.n, bool)
+        keep[self.valid_rows()] = True
+        W[~keep] = np.nan
+        self.W = W
+        self.S = np.full((self.m, self.m), np.nan, T)
+        self.V = np.full((f.n, self.m), np.nan, T)
 
-    def factor_solve(self):
+    def innovation_rows(self, k0, k1):
         f = self.f
         T = f.T
-        S = self._t["S"].numpy().astype(T)
-        assert np.all(np.isfinite(S))
-        L = np.linalg.cholesky(S)
-        Linv = np.linalg.inv(L)
-        rows = self.own_rows()
-        V = self._t["V"]
-        V.fill_(float("nan"))
-        V[rows] = torch.from_numpy(self.W[rows] @ Linv.T)
-        self.y = Linv @ self.nu
+        sub = self.indices[k0:k1]
+        rows = f.H_times(self.W, sub, False) if sub else np.zeros((0, self.m), T)
+        for j in range(len(sub)):
+            rows[2 * j, 2 * (k0 + j)] += T(f.sigma_pixel_2)
+            rows[2 * j + 1, 2 * (k0 + j) + 1] += T(f.sigma_pixel_2)
+        self.S[2 * k0:2 * k1] = rows
+        if self.plane:                                    # the plane rows read camera rows of W: every rank forms them
+            M = len(self.indices)
+            for e, r in enumerate((1, 4, 6)):
+                self.S[2 * M + e] = self.W[r]
+                self.S[2 * M + e, 2 * M + e] += T(0.00001)
+        return rows
 
-    def downdate(self):
+    def set_S_rows(self, row0, arr):
+        self.S[row0:row0 + arr.shape[0]] = arr
+
+    def factor(self):
+        assert np.all(np.isfinite(self.S))
+        L = np.linalg.cholesky(self.S.astype(np.float64)).astype(self.f.T)
+        self.Linv_T = np.linalg.inv(L).T.astype(self.f.T)  # Z = L^-T
+        self.y = (self.Linv_T.T @ self.nu).astype(self.f.T)
+
+    def solve_chunk(self, c0, c1):
+        rows = self.valid_rows()
+        self.V[rows, c0:c1] = self.W[rows] @ self.Linv_T[:, c0:c1]
+        return self.V[self.own_r.start:self.own_r.stop, c0:c1].copy()
+
+    def set_V_rows(self, rows, c0, c1, arr):
+        self.V[rows.start:rows.stop, c0:c1] = arr
+
+    def downdate_chunk(self, c0, c1):
+        Vg = self.V[:, c0:c1]
+        assert np.all(np.isfinite(Vg))
+        rows = self.valid_rows()
+        self.f.Sigma[rows, :] = self.f.Sigma[rows, :] - Vg[rows] @ Vg.T
+
+    def finish_update(self):
         f = self.f
-        T = f.T
-        V = self._t["V"].numpy().astype(T)
-        assert np.all(np.isfinite(V))
-        f.mu = f.mu + V @ self.y
-        rows = self.own_rows()
-        f.Sigma[rows, :] = f.Sigma[rows, :] - V[rows] @ V.T
+        assert np.all(np.isfinite(self.V))
+        f.mu = f.mu + self.V @ self.y
         f.normalize_quaternion()
         self._poison()

@@ -1,9 +1,10 @@
-"""The N > 1 path: row-panel sharding with all-gathers of H, S and V.
+"""The N > 1 path: row-panel sharding with all-gathers of H, S, V (+ linearity flags, + Sigma panels on re-balance).
 
-CPU (gloo, world_size 2 and 4): the real orchestration (`ShardedStep`, `all_gather_rows`) over an
-oracle-backed stand-in that poisons every row a rank does not own -> must equal the unsharded
-oracle.  GPU: world 1 in-process against the plain HIP path, and two ranks sharing the one GPU of
-the box over gloo against the plain HIP path."""
+CPU (gloo, world_size 2 and 4): `sharded.ShardProtocol` -- the protocol the library implements, in numpy -- over an
+oracle-backed rank that poisons everything it does not own: uneven partitions, measured subsets, XYZ features, the
+plane rows, add / remove / convert under sharding and the re-balance must all equal the unsharded oracle.
+GPU: the library's sharded step (csrc/ekf_capi.hip) with world 1 in-process, and with 2 / 4 ranks sharing the one GPU
+of the box (collectives through gloo and host memory) against the plain HIP path and the oracle."""
 import os
 import socket
 import sys
@@ -20,6 +21,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 import ekf_oracle as o  # noqa: E402
+from helpers import bound, relf  # noqa: E402
 
 
 def free_port():
@@ -28,60 +30,175 @@ def free_port():
         return s.getsockname()[1]
 
 
-from helpers import bound, relf  # noqa: E402
-
-
-def reference_run(n_feat, frames, dtype):
-    f = o.build_scenario(o.StructuredFilter, o.Config.kinect(), n_feat, dtype)
-    zs = []
+# ---------------------------------------------------------------------------------------------
+# the scenario both sides run: frames of predict + update on changing measured subsets, with XYZ conversions,
+# removals, additions (-> imbalance -> re-balance) on the way
+# ---------------------------------------------------------------------------------------------
+def scenario_events(n_feat, frames, seed=1236):
+    """Deterministic schedule: per frame (measured subset rule, plane?, resize event)."""
+    rng = np.random.default_rng(seed)
+    ev = []
     for k in range(frames):
-        f.predict()
-        idx = list(range(n_feat))
-        z = o.synthetic_measurements(f, idx, seed=500 + k, sigma=0.5)
-        zs.append(z)
-        f.update(z, idx)
-    return f, zs
+        e = {"subset": k % 3, "plane": k == 2, "remove": [], "add": [], "convert": k in (1, 4)}
+        if k in (2, 5):
+            e["remove_frac"] = 0.15
+            e["add"] = [(float(rng.uniform(20, 300)), float(rng.uniform(20, 220))) for _ in range(max(3, n_feat // 2))]
+        ev.append(e)
+    return ev
 
 
-def _cpu_worker(rank, world, port, n_feat, frames, zs, out):
+def pick(vis, rule):
+    if rule == 0:
+        return list(vis)
+    if rule == 1:
+        return list(vis[::2])
+    return list(vis[1::3]) + ([] if len(vis) < 4 else [])
+
+
+class PlainOracle:
+    """The unsharded oracle driven through the same interface as ShardProtocol."""
+
+    def __init__(self, f):
+        self.f = f
+
+    def predict(self):
+        f = self.f
+        Ft, Q = f._motion((0, 0, 0), (0, 0, 0), False)
+        f.predict_covariance(Ft, Q)
+        f.mu[0:13] = o.predict_state(f.mu[0:13], (0, 0, 0), (0, 0, 0), f.dT, f.T)
+        o.DenseFilter.measure(f)
+
+    def visible(self):
+        return self.f.visible_indices()
+
+    def update(self, z, idx, plane):
+        self.f.update(z, idx, plane=plane)
+
+    def convert_all(self):
+        return self.f.convert2xyz_if_linear_all()
+
+    def remove_features(self, idx):
+        for i in reversed(sorted(idx)):
+            self.f.remove_feature(i)
+
+    def add_feature(self, u, v):
+        return self.f.add_feature(u, v)
+
+
+def run_scenario(driver, visible, n_feat, frames, seed_z=4000, force_linear=None):
+    """Drives `driver` (PlainOracle or ShardProtocol) through the schedule.  `force_linear(frame)` lets the caller
+    shrink a few Sigma(rho, rho) so that conversions actually happen."""
+    events = scenario_events(n_feat, frames)
+    log = []
+    for k, e in enumerate(events):
+        driver.predict()
+        vis = visible()
+        idx = pick(vis, e["subset"])
+        zrng = np.random.default_rng(seed_z + k)
+        z = zrng.normal(0.0, 0.5, size=2 * len(idx))          # noise; the caller adds h
+        log.append((k, idx, z, e))
+        yield k, idx, z, e
+
+
+def cpu_scenario(make_driver, n_feat, frames, world=1, rank=0):
+    f = o.build_scenario(o.StructuredFilter, o.Config.kinect(), n_feat, np.float64)
+    drv, fobj = make_driver(f)
+    rng = np.random.default_rng(77)
+    events = scenario_events(n_feat, frames)
+    for k, e in enumerate(events):
+        drv.predict()
+        vis = fobj.visible_indices()
+        idx = pick(vis, e["subset"])
+        hz = np.concatenate([fobj.features[i].h for i in idx]) if idx else np.zeros(0)
+        z = hz + np.random.default_rng(4000 + k).normal(0.0, 0.5, size=hz.shape)
+        drv.update(z, idx, e["plane"])
+        if e["convert"]:
+            # make a few inverse-depth features pass the linearity test: the owner's Sigma(rho, rho) decides, so
+            # the tweak is applied through mu (replicated): move rho so that the index drops (same on every rank)
+            for i in range(1, len(fobj.features), 4):
+                ft = fobj.features[i]
+                if ft.coding == o.INV:
+                    fobj.mu[ft.position_in_state + 5] = 3.0
+            drv.convert_all()
+        if "remove_frac" in e:
+            N = len(fobj.features)
+            drop = sorted(rng.choice(N, size=max(1, int(N * e["remove_frac"])), replace=False).tolist())
+            drv.remove_features(drop)
+            for (u, v) in e["add"]:
+                assert drv.add_feature(u, v) == 1
+    return fobj
+
+
+def _cpu_worker(rank, world, port, n_feat, frames, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from __graft_entry__ import load_package
     load_package()
-    from ekf_monoslam_amd.sharded import ShardedStep
+    from ekf_monoslam_amd.sharded import ShardProtocol
     from sharded_common import OracleShardBackend
-    f = o.build_scenario(o.StructuredFilter, o.Config.kinect(), n_feat, np.float64)
-    step = ShardedStep(OracleShardBackend(f, rank, world))
-    for k in range(frames):
-        step.step(zs[k])
-    rows = step.b.own_rows()
-    out[rank] = (f.mu.copy(), rows, f.Sigma[rows].copy())
+    holder = {}
+
+    def make(f):
+        b = OracleShardBackend(f)
+        p = ShardProtocol(b, rank, world)
+        holder["p"] = p
+        return p, f
+    f = cpu_scenario(make, n_feat, frames, world, rank)
+    p = holder["p"]
+    rows = np.r_[0:f.camera_dim, p.own_rows().start:p.own_rows().stop]
+    out[rank] = (f.mu.copy(), rows, f.Sigma[rows].copy(), p.rebalances, list(p.fb),
+                 [ft.coding for ft in f.features])
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_orchestration_matches_unsharded_oracle_gloo(world):
-    n_feat, frames = 8, 3
-    ref, zs = reference_run(n_feat, frames, np.float64)
+@pytest.mark.parametrize("world,n_feat", [(2, 9), (4, 14), (4, 3)])
+def test_shard_protocol_matches_unsharded_oracle_gloo(world, n_feat):
+    """Uneven partitions (9 over 2, 14 over 4, 3 features over 4 ranks: an empty rank), subsets, plane rows, XYZ
+    conversions, removals and additions, re-balance: every rank's rows must equal the unsharded oracle."""
+    frames = 7
+    ref = cpu_scenario(lambda f: (PlainOracle(f), f), n_feat, frames)
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_cpu_worker, args=(world, free_port(), n_feat, frames, zs, out), nprocs=world, join=True)
+    mp.spawn(_cpu_worker, args=(world, free_port(), n_feat, frames, out), nprocs=world, join=True)
     seen = np.zeros(ref.n, bool)
     for rank in range(world):
-        mu, rows, S_rows = out[rank]
-        assert bound("mu, ref.mu", relf(mu, ref.mu), 1e-9)
-        assert bound("S_rows, ref.Sigma[rows]", relf(S_rows, ref.Sigma[rows]), 1e-8)
+        mu, rows, S_rows, rebal, fb, coding = out[rank]
+        assert coding == [ft.coding for ft in ref.features]
+        assert relf(mu, ref.mu) < 1e-9, rank
+        assert np.all(np.isfinite(S_rows)) and relf(S_rows, ref.Sigma[rows]) < 1e-8, rank
+        assert fb == out[0][4]                               # every rank tracks the same boundaries
         seen[rows] = True
-    assert seen.all()                      # the panels cover every row of Sigma
+    assert seen.all()                                        # the panels cover every row of Sigma
+    if n_feat >= 9:
+        assert any(c == o.XYZ for c in out[0][5])            # the schedule did convert something
+        assert out[0][3] >= 1                                # ... and growth at the tail forced a re-balance
 
 
-def _mk_hip(pkg, n_feat, px0=None):
+def test_partition_balances_rows_not_features():
+    from __graft_entry__ import load_package
+    load_package()
+    from ekf_monoslam_amd.sharded import partition_by_rows
+    # 4 XYZ features (3 rows) then 4 inverse-depth ones (6 rows): half of the ROWS is after feature 5
+    sizes = [3, 3, 3, 3, 6, 6, 6, 6]
+    pos = list(14 + np.concatenate([[0], np.cumsum(sizes)[:-1]]))
+    n = 14 + sum(sizes)
+    assert partition_by_rows(pos, n, 14, 2) == [0, 5, 8]
+    assert partition_by_rows(pos, n, 14, 1) == [0, 8]
+    assert partition_by_rows([], 14, 14, 3) == [0, 0, 0, 0]
+    fb = partition_by_rows(pos, n, 14, 4)
+    assert fb[0] == 0 and fb[-1] == 8 and all(a <= b for a, b in zip(fb, fb[1:]))
+
+
+# ---------------------------------------------------------------------------------------------
+# GPU: the library's sharded step
+# ---------------------------------------------------------------------------------------------
+def _mk_hip(pkg, n_feat, px0=None, capacity=None, dtype=np.float32):
     """HIP filter on the scenario of o.build_scenario (velocities set, features added in order), or -- with
     px0 -- on the bench's synthetic stream (camera at rest, its pixels)."""
     cfg = o.Config.kinect()
-    flt = pkg.VSlamFilter(pkg.kinect_config(), capacity_features=n_feat, dtype=np.float32)
+    flt = pkg.VSlamFilter(pkg.kinect_config(), capacity_features=capacity or n_feat, dtype=dtype)
     flt.setDt(1.0 / 30.0)
     if px0 is None:
         mu = flt.getFullState()
@@ -94,25 +211,130 @@ def _mk_hip(pkg, n_feat, px0=None):
     return flt
 
 
-def _gpu_worker(rank, world, port, n_feat, frames, z_np, out, px0=None):
+def hip_scenario(pkg, flt, ref, frames, dtype):
+    """The schedule of cpu_scenario on a HIP filter (sharded or plain) with the oracle `ref` run beside it: the
+    measured sets and resize decisions come from the oracle, so every rank (and the plain path) sees the same calls.
+    Returns the per-frame measured sets for inspection."""
+    rng = np.random.default_rng(77)
+    events = scenario_events(len(ref.features), frames)
+    for k, e in enumerate(events):
+        ref.predict()
+        flt.predict()
+        vis = ref.visible_indices()
+        idx = pick(vis, e["subset"])
+        hz = np.concatenate([ref.features[i].h for i in idx]) if idx else np.zeros(0)
+        z = (hz + np.random.default_rng(4000 + k).normal(0.0, 0.5, size=hz.shape)).astype(dtype)
+        ref.update(z, idx, plane=e["plane"])
+        flt.update(z, idx, plane_constraint=e["plane"])
+        if e["convert"]:
+            for i in range(1, len(ref.features), 4):
+                ft = ref.features[i]
+                if ft.coding == o.INV:
+                    ref.mu[ft.position_in_state + 5] = 3.0
+                    flt.setStateSegment(ft.position_in_state + 5, [3.0])
+            a = ref.convert2xyz_if_linear_all()
+            b = flt.convert2XYZ_ifLinearAll()
+            assert a == b, (k, a, b)
+        if "remove_frac" in e:
+            N = len(ref.features)
+            drop = sorted(rng.choice(N, size=max(1, int(N * e["remove_frac"])), replace=False).tolist())
+            for i in reversed(drop):
+                ref.remove_feature(i)
+            flt.removeFeatures(drop)
+            for (u, v) in e["add"]:
+                assert ref.add_feature(u, v) == 1 and flt.addFeature((u, v)) == 1
+        assert flt.numOfFeatures() == len(ref.features) and flt.stateDim() == ref.n
+
+
+def _gpu_worker(rank, world, port, n_feat, frames, dtype_name, out, capacity=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from __graft_entry__ import load_package
     pkg = load_package()
-    from ekf_monoslam_amd.sharded import HipShardBackend, ShardedStep
-    flt = _mk_hip(pkg, n_feat, px0)
-    b = HipShardBackend(flt, rank, world)
-    step = ShardedStep(b)
-    d_z = torch.from_numpy(z_np).cuda()
-    for k in range(frames):
-        step.step(d_z[k].data_ptr())
-        flt.synchronize()
-    mu = flt.getFullState()
-    r0 = b.camera_dim + rank * b.rows_per_rank
-    rows = np.r_[0:b.camera_dim, r0:r0 + b.rows_per_rank]
+    from ekf_monoslam_amd import sharded
+    dtype = np.dtype(dtype_name).type
+    flt = _mk_hip(pkg, n_feat, capacity=capacity, dtype=dtype)
+    ag = sharded.configure(flt, rank, world)
+    ref = o.build_scenario(o.StructuredFilter, o.Config.kinect(), n_feat, dtype)
+    hip_scenario(pkg, flt, ref, frames, dtype)
+    flt.synchronize()
+    info = sharded.shard_info(flt)
+    rows = np.r_[0:14, info.row_begin:info.row_end]
     S = flt.getFullSigma()
-    out[rank] = (mu, rows, S[rows])
+    pad, asym, big = flt.checkInvariants()
+    out[rank] = (flt.getFullState(), rows, S[rows], info.rebalances, (info.f_begin, info.f_end), ag.calls, pad,
+                 ref.mu.copy(), ref.Sigma[rows].copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_hip_shard_world1_matches_plain_path_and_oracle(dtype):
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from ekf_monoslam_amd import sharded
+    n_feat, frames = 40, 7
+    outs = []
+    for shard in (False, True):
+        flt = _mk_hip(pkg, n_feat, capacity=2 * n_feat + 8, dtype=dtype)
+        if shard:
+            sharded.configure(flt, 0, 1)
+        ref = o.build_scenario(o.StructuredFilter, o.Config.kinect(), n_feat, dtype)
+        hip_scenario(pkg, flt, ref, frames, dtype)
+        flt.synchronize()
+        outs.append((flt.getFullState(), flt.getFullSigma(), ref))
+    (mu_p, S_p, ref), (mu_s, S_s, _) = outs
+    f32 = dtype == np.float32
+    assert bound("sharded(world 1) mu vs plain path", relf(mu_s, mu_p), 1e-5 if f32 else 1e-12)
+    assert bound("sharded(world 1) Sigma vs plain path", relf(S_s, S_p), 2e-4 if f32 else 1e-10)
+    assert bound("sharded(world 1) mu vs oracle", relf(mu_s, ref.mu), 5e-5 if f32 else 1e-11)
+    assert bound("sharded(world 1) Sigma vs oracle", relf(S_s, ref.Sigma), 2e-3 if f32 else 1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n_feat,dtype", [(2, 45, np.float64), (3, 50, np.float32), (4, 60, np.float32)])
+def test_hip_shard_ranks_on_one_gpu_dynamic_stream_vs_oracle(world, n_feat, dtype):
+    """configs[4] semantics at oracle size: several ranks (sharing the one GPU; collectives through gloo), features
+    that do NOT divide by the world size, measured subsets, the plane rows, XYZ conversions, removals and additions
+    every few frames, capacity > N, an automatic re-balance -- every rank's rows against the oracle."""
+    frames = 7
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gpu_worker, args=(world, free_port(), n_feat, frames, np.dtype(dtype).name, out, 2 * n_feat + 8),
+             nprocs=world, join=True)
+    f32 = dtype == np.float32
+    covered = []
+    for rank in range(world):
+        mu, rows, S_rows, rebal, frange, calls, pad, mu_ref, S_ref = out[rank]
+        assert np.all(np.isfinite(mu)) and np.all(np.isfinite(S_rows))
+        assert bound("rank mu vs oracle", relf(mu, mu_ref), 5e-5 if f32 else 1e-11)
+        assert bound("rank Sigma rows vs oracle", relf(S_rows, S_ref), 2e-3 if f32 else 1e-9)
+        assert pad == 0.0                                    # capacity > N: nothing leaks outside the live block
+        assert calls > 0 and rebal >= 1
+        covered.append(frange)
+    assert covered[0][0] == 0 and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))     # contiguous, complete
+
+
+def _gpu_static_worker(rank, world, port, n_feat, frames, z_np, px0, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from ekf_monoslam_amd import sharded
+    flt = _mk_hip(pkg, n_feat, px0)
+    sharded.configure(flt, rank, world)
+    d_z = torch.from_numpy(z_np).cuda()
+    idx = np.arange(n_feat, dtype=np.int32)
+    for k in range(frames):
+        flt.predict()
+        sharded.shard_update(flt, d_z[k].data_ptr(), idx)
+    flt.synchronize()
+    info = sharded.shard_info(flt)
+    rows = np.r_[0:14, info.row_begin:info.row_end]
+    out[rank] = (flt.getFullState(), rows, flt.getFullSigma()[rows])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -128,55 +350,13 @@ def _plain_hip_run(n_feat, frames, z_np, px0=None):
     return flt.getFullState(), flt.getFullSigma()
 
 
-def _stream(n_feat, frames):
-    ref = o.build_scenario(o.StructuredFilter, o.Config.kinect(), n_feat, np.float32)
-    zs = []
-    for k in range(frames):
-        ref.predict()
-        z = o.synthetic_measurements(ref, list(range(n_feat)), seed=700 + k, sigma=0.5)
-        zs.append(z)
-        ref.update(z, list(range(n_feat)))
-    return ref, np.stack(zs).astype(np.float32)
-
-
 @pytest.mark.gpu
-def test_hip_shard_world1_matches_plain_path():
-    from __graft_entry__ import load_package
-    pkg = load_package()
-    from ekf_monoslam_amd.sharded import HipShardBackend, ShardedStep
-    n_feat, frames = 40, 3
-    ref, z_np = _stream(n_feat, frames)
-    mu_p, S_p = _plain_hip_run(n_feat, frames, z_np)
-    flt = _mk_hip(pkg, n_feat)
-    step = ShardedStep(HipShardBackend(flt, 0, 1))
-    d_z = torch.from_numpy(z_np).cuda()
-    for k in range(frames):
-        step.step(d_z[k].data_ptr())
-    flt.synchronize()
-    assert bound("flt.getFullState(), mu_p", relf(flt.getFullState(), mu_p), 1e-5)
-    assert bound("flt.getFullSigma(), S_p", relf(flt.getFullSigma(), S_p), 2e-4)
-    assert bound("flt.getFullSigma(), ref.Sigma", relf(flt.getFullSigma(), ref.Sigma), 1e-3)
-
-
-@pytest.mark.gpu
-def test_hip_shard_two_ranks_on_one_gpu_match_plain_path():
-    n_feat, frames = 40, 3
-    ref, z_np = _stream(n_feat, frames)
-    mu_p, S_p = _plain_hip_run(n_feat, frames, z_np)
-    mgr = mp.Manager()
-    out = mgr.dict()
-    mp.spawn(_gpu_worker, args=(2, free_port(), n_feat, frames, z_np, out), nprocs=2, join=True)
-    for rank in range(2):
-        mu, rows, S_rows = out[rank]
-        assert bound("mu, mu_p", relf(mu, mu_p), 1e-5)
-        assert bound("S_rows, S_p[rows]", relf(S_rows, S_p[rows]), 2e-4)
-
-
-@pytest.mark.gpu
-def test_hip_shard_four_ranks_mid_size_match_plain_path():
-    """Row panels that do not sit on tile boundaries (150 features = 900 rows per rank), a chain of 10 block
-    steps in chunks, four ranks sharing the GPU over gloo: every rank's rows must match the plain pipelined path."""
-    n_feat, frames, world = 600, 2, 4
+@pytest.mark.parametrize("world,n_feat", [(4, 1000), (3, 601)])
+def test_hip_shard_full_size_matches_plain_path(world, n_feat):
+    """BASELINE configs[3] at full size (N = 1000, n = 6014, 16 block steps in 3 chunks) on 4 ranks sharing the GPU,
+    and a size whose panels sit on no tile boundary with an uneven split (601 over 3): every rank's rows must match
+    the plain pipelined single-GPU path."""
+    frames = 2
     from __graft_entry__ import load_package
     pkg = load_package()
     from ekf_monoslam_amd import synthetic
@@ -185,21 +365,34 @@ def test_hip_shard_four_ranks_mid_size_match_plain_path():
     mu_p, S_p = _plain_hip_run(n_feat, frames, z_np, px0)
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_gpu_worker, args=(world, free_port(), n_feat, frames, z_np, out, px0), nprocs=world, join=True)
+    mp.spawn(_gpu_static_worker, args=(world, free_port(), n_feat, frames, z_np, px0, out), nprocs=world, join=True)
+    seen = np.zeros(14 + 6 * n_feat, bool)
     for rank in range(world):
         mu, rows, S_rows = out[rank]
         assert np.all(np.isfinite(mu))
-        assert bound("mu, mu_p", relf(mu, mu_p), 2e-5)
-        assert bound("S_rows, S_p[rows]", relf(S_rows, S_p[rows]), 5e-4)
+        assert bound("rank mu vs plain path", relf(mu, mu_p), 2e-5)
+        assert bound("rank Sigma rows vs plain path", relf(S_rows, S_p[rows]), 5e-4)
+        seen[rows] = True
+    assert seen.all()
 
 
 @pytest.mark.gpu
-def test_shard_rejects_unsupported_layouts():
+def test_shard_argument_checks():
     from __graft_entry__ import load_package
     pkg = load_package()
+    from ekf_monoslam_amd import sharded
     flt = pkg.VSlamFilter(pkg.kinect_config(), capacity_features=8)
     for (u, v) in o.synthetic_pixels(o.Config.kinect(), 5):
         flt.addFeature((u, v))
-    assert flt._lib.ekf_shard_configure(flt._h, 0, 2) == 6        # 5 features over 2 ranks
-    assert flt._lib.ekf_shard_configure(flt._h, 0, 5) == 0
-    assert flt._lib.ekf_shard_factor_solve(flt._h) == 4            # phase order is enforced
+    lib = flt._lib
+    assert lib.ekf_shard_configure(flt._h, 2, 2, None, None) == 1          # rank out of range
+    assert lib.ekf_shard_configure(flt._h, 0, 2, None, None) == 1          # world > 1 without a callback
+    assert lib.ekf_shard_rebalance(flt._h) == 4                            # not configured
+    sharded.configure(flt, 0, 1)
+    info = sharded.shard_info(flt)
+    assert (info.f_begin, info.f_end, info.row_begin, info.row_end) == (0, 5, 14, 44)
+    with pytest.raises(pkg.EkfError):                                      # update before predict
+        flt.update(np.zeros(2, np.float32), [0])
+    flt.predict()
+    with pytest.raises(pkg.EkfError):                                      # unsorted list
+        flt.update(np.zeros(4, np.float32), [3, 1])
