@@ -170,6 +170,8 @@ struct Filter : FilterBase {
   bool own_stream = false;
   hipStream_t stream_b = nullptr, stream_c = nullptr;   // solve pieces / downdate pieces, overlapped with the chain
   hipEvent_t ev_chain[8] = {}, ev_solve[8] = {}, ev_b = nullptr, ev_c = nullptr, ev_wu = nullptr;
+  hipStream_t stream_g = nullptr;                       // sharded step: the all-gathers of V_g, beside the rank's solves
+  hipEvent_t ev_gath[8] = {}, ev_g = nullptr;
   int opt_chain_mask = 0;                               // 1: chain of chunks >= 1 on the reserved CUs only (measured slower: the trailing updates want more CUs)
   int solve64_off = 0, solve6464_off = 0, tri64_off = 0, tri64_count = 0;
   int opt_split_bf16 = 0;                               // EKF_OPT_SPLIT_BF16: downdate on the bf16 matrix pipe, 3 x bf16 per operand
@@ -227,6 +229,9 @@ struct Filter : FilterBase {
     if (own_stream && stream) hipStreamDestroy(stream);
     if (stream_b) hipStreamDestroy(stream_b);
     if (stream_c) hipStreamDestroy(stream_c);
+    if (stream_g) hipStreamDestroy(stream_g);
+    for (auto e : ev_gath) if (e) hipEventDestroy(e);
+    if (ev_g) hipEventDestroy(ev_g);
     for (auto e : ev_chain) if (e) hipEventDestroy(e);
     for (auto e : ev_solve) if (e) hipEventDestroy(e);
     if (ev_b) hipEventDestroy(ev_b);
@@ -263,6 +268,7 @@ struct Filter : FilterBase {
     hipStreamSynchronize(stream);
     hipStreamSynchronize(stream_b);
     hipStreamSynchronize(stream_c);
+    if (stream_g) hipStreamSynchronize(stream_g);
     for (auto& p : pending) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { prof_ms[p.kid] += ms; prof_cnt[p.kid] += 1; }
@@ -1528,6 +1534,7 @@ struct Filter : FilterBase {
   T *d_stage_send = nullptr, *d_stage_recv = nullptr;
   size_t stage_slot = 0;                                   // scalars per slot the staging buffers hold
   int sh_rebalances = 0;
+  bool sh_force = false;                                   // world 1 with a callback and EKF_SHARD_FORCE_COLLECTIVE=1: every exchange still runs (profiling the collective path on one GPU)
   std::vector<int> sh_list;                                // host copy of the measured list resident in d_midx
   double sh_imbalance_limit = 1.125;                       // re-partition when a rank owns > 1.125 x the mean rows
 
@@ -1552,6 +1559,7 @@ struct Filter : FilterBase {
     if (slot_elems <= stage_slot) return EKF_OK;
     HIPCHK(hipStreamSynchronize(stream));
     if (stream_b) HIPCHK(hipStreamSynchronize(stream_b));
+    if (stream_g) HIPCHK(hipStreamSynchronize(stream_g));
     if (d_stage_send) HIPCHK(hipFree(d_stage_send));
     if (d_stage_recv) HIPCHK(hipFree(d_stage_recv));
     d_stage_send = d_stage_recv = nullptr;
@@ -1563,8 +1571,9 @@ struct Filter : FilterBase {
   }
 
   // the collective: slot g of d_stage_recv <- d_stage_send of rank g, ordered on stream `st`
+  bool exchanges() const { return sh_world > 1 || sh_force; }
   int all_gather(size_t slot_elems, hipStream_t st) {
-    if (sh_world == 1) return EKF_OK;
+    if (!exchanges()) return EKF_OK;
     if (!sh_ag) FAIL(EKF_ERR_STATE, "sharded filter without an all-gather callback (ekf_shard_configure)");
     const int rc = sh_ag(sh_ctx, d_stage_send, d_stage_recv, slot_elems * sizeof(T), st);
     if (rc != 0) FAIL(EKF_ERR_DEVICE, "the all-gather callback reported a failure");
@@ -1574,7 +1583,7 @@ struct Filter : FilterBase {
   // rows [tab.start[g], +tab.count[g]) x columns [col0, col0 + ncols) of `buf` (row stride ldb): own range out,
   // everybody else's in
   int exchange_rows(T* buf, int ldb, const ShardTab& tab, int col0, int ncols, hipStream_t st, int kid) {
-    if (sh_world == 1) return EKF_OK;
+    if (!exchanges()) return EKF_OK;
     int maxrows = 0;
     for (int g = 0; g < sh_world; ++g) maxrows = std::max(maxrows, tab.count[g]);
     if (maxrows == 0) return EKF_OK;
@@ -1613,6 +1622,12 @@ struct Filter : FilterBase {
     HIPCHK(hipSetDevice(device));
     sh_rank = rank; sh_world = world; sh_ag = fn; sh_ctx = ctx;
     sh_on = true;
+    if (const char* e = getenv("EKF_SHARD_FORCE_COLLECTIVE")) sh_force = (atoi(e) != 0) && fn != nullptr;
+    if (!stream_g) {
+      HIPCHK(hipStreamCreateWithFlags(&stream_g, hipStreamNonBlocking));
+      for (auto& e : ev_gath) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&ev_g, hipEventDisableTiming));
+    }
     // every rank was built by the same calls, so all of Sigma is valid everywhere right now: any partition will do
     partition_by_rows();
     have_meas = false;
@@ -1650,7 +1665,7 @@ struct Filter : FilterBase {
   int shard_rebalance() override {
     HIPCHK(hipSetDevice(device));
     if (!sh_on) FAIL(EKF_ERR_STATE, "ekf_shard_configure first");
-    if (sh_world > 1 && N > 0) {
+    if (exchanges() && N > 0) {
       const ShardTab tab = row_tab();
       const int cw = 4096;                                 // column block: bounds the staging buffers
       const int vec = 16 / (int)sizeof(T);
@@ -1697,7 +1712,7 @@ struct Filter : FilterBase {
       k_measure<T><<<(f1 - f0 + 63) / 64, 64, 0, stream>>>(mu(), d_pos, d_coding, f0, f1, cam, d_h, d_Hc, d_Hf, d_flags);
     }
     HIPCHK(hipGetLastError());
-    if (sh_world > 1 && N > 0) {                           // "reassemble H": h, compact Jacobians, flags of every feature
+    if (exchanges() && N > 0) {                            // "reassemble H": h, compact Jacobians, flags of every feature
       const ShardTab tab = feature_tab();
       int mx = 0;
       for (int g = 0; g < sh_world; ++g) mx = std::max(mx, tab.count[g]);
@@ -1799,11 +1814,37 @@ struct Filter : FilterBase {
     int rc = exchange_rows(d_Y, ldy, stab, 0, m_pad, stream, KID_GATHER_S);     // "reassemble S"
     if (rc) return rc;
 
-    // replicated chain in column chunks, the rank's share of every chunk (solve, W update, gather of V_g, downdate)
-    // beside it on the CU-masked second stream -- the structure of Filter::update
+    // Replicated chain in column chunks; the rank's share of every chunk beside it:
+    //   second stream (CU-masked):  solve V_g rows, W update rows, ... downdate of the PREVIOUS chunk
+    //   gather stream:              all-gather of the own rows of V_g (needs the solve; the downdate needs it)
+    // so a gather travels while the next chunk is being solved, and only the last chunk's solve -> gather -> downdate
+    // is exposed after the chain.  With 1 / world of the GEMM work per rank many narrow chunks are affordable: the
+    // exposed tail shrinks with the width of the last one.
     const int nsteps = m_pad / nb;
     int cend[8];
-    const int nchunks = plan_chunks(nsteps, cend);
+    int nchunks;
+    {
+      const bool pipe = (opt_pipeline < 0) ? (nsteps >= 4) : (opt_pipeline != 0);
+      if (!pipe || !stream_b || !stream_g) {
+        cend[0] = nsteps;
+        nchunks = 1;
+      } else if (env_nchunks > 0 && env_chunks[env_nchunks - 1] == nsteps) {
+        for (int g = 0; g < env_nchunks; ++g) cend[g] = env_chunks[g];
+        nchunks = env_nchunks;
+      } else {
+        // chunk count by world size: every chunk costs a pass over the remaining columns of W and re-reads the Sigma
+        // panel, and a rank's share of that work is 1 / world -- two ranks afford 4 chunks, four and more 8
+        const int cap = sh_world <= 1 ? 3 : (sh_world <= 2 ? 4 : 8);
+        const int want = std::min(cap, std::max(2, (nsteps + 1) / 2));
+        nchunks = 0;
+        int prev = 0;
+        for (int g = 0; g < want; ++g) {
+          int e = (int)(((long long)nsteps * (g + 1) + want - 1) / want);
+          if (g + 1 == want) e = nsteps;
+          if (e > prev) { cend[nchunks++] = e; prev = e; }
+        }
+      }
+    }
     ChunkTab tab{nchunks, {}};
     int strip_rows = 0;
     for (int g = 0; g < nchunks; ++g) {
@@ -1816,22 +1857,33 @@ struct Filter : FilterBase {
       dim3 grid((m_pad + 255) / 256, strip_rows);
       k_set_identity_strip<T><<<grid, 256, 0, stream>>>(Zs, ldy, m_pad, tab); }
     const ShardTab rtab = row_tab();
+    auto downdate_chunk = [&](int c0, int c1, hipStream_t ss) {
+      for (int q = 0; q < 2; ++q) {                        // Sigma[rows, :] -= V_g[rows] V_g^T: camera tile, own panel
+        const Rows& rr = ranges[q];
+        if (rr.count == 0) continue;
+        Scope sc(this, KID_DOWNDATE, ss);
+        if (sc.on) prof_work[KID_DOWNDATE] += 2.0 * rr.count * double(n) * (std::min(c1, m) - std::min(c0, m));
+        gemm<ROLE_DOWNDATE, false>(d_V + (size_t)rr.r0 * ldy + c0, ldy, d_V + c0, ldy, S() + (size_t)rr.r0 * ld, ld, rr.count,
+                                   npad_live, c1 - c0, T(-1), T(1), 0, 0, 0, 0, 0, ss);
+      }
+    };
     int step = 0;
-    bool b_inflight = false;
+    bool side_busy = false;
+    int pend_c0 = -1, pend_c1 = -1, pend_g = -1;           // overlapped chunk whose downdate is still to be issued
     for (int gi = 0; gi < nchunks; ++gi) {
       const int c0 = step * nb, c1 = cend[gi] * nb, width = c1 - c0;
       chain_steps(step, cend[gi], c0, c1, m, m_pad, stream);
       step = cend[gi];
-      const bool overlap = (stream_b != nullptr) && (gi + 1 < nchunks);
+      const bool overlap = (gi + 1 < nchunks);
       hipStream_t ss = overlap ? stream_b : stream;
       if (overlap) {
         HIPCHK(hipEventRecord(ev_chain[gi], stream));
         HIPCHK(hipStreamWaitEvent(stream_b, ev_chain[gi], 0));
-        b_inflight = true;
-      } else if (b_inflight) {                             // the last chunk needs every earlier W update and downdate
+        side_busy = true;
+      } else if (side_busy) {
+        // the last chunk runs on the main stream: it needs every earlier W update (second stream) first
         HIPCHK(hipEventRecord(ev_b, stream_b));
         HIPCHK(hipStreamWaitEvent(stream, ev_b, 0));
-        b_inflight = false;
       }
       for (const Rows& rr : ranges) {
         if (rr.count == 0) continue;
@@ -1839,21 +1891,45 @@ struct Filter : FilterBase {
         { Scope sc(this, KID_SOLVE, ss);
           gemm<ROLE_SOLVE, true>(d_W + off + c0, ldy, Zs + c0, ldy, d_V + off + c0, ldy, rr.count, width, width, T(1), T(0),
                                  0, 0, 0, 1, 0, ss); }
-        if (c1 < m_pad) {
+      }
+      if (overlap) {
+        // own rows of V_g are final: their gather starts now, on the gather stream ...
+        HIPCHK(hipEventRecord(ev_solve[gi], stream_b));
+        HIPCHK(hipStreamWaitEvent(stream_g, ev_solve[gi], 0));
+        rc = exchange_rows(d_V, ldy, rtab, c0, width, stream_g, KID_GATHER_V);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(ev_gath[gi], stream_g));
+      }
+      if (c1 < m_pad) {                                    // ... while the W update (needs the OWN rows of V_g only) goes on
+        for (const Rows& rr : ranges) {
+          if (rr.count == 0) continue;
+          const size_t off = (size_t)rr.r0 * ldy;
           Scope sc(this, KID_WUPDATE, ss);
           gemm<ROLE_WUPDATE, false>(d_V + off + c0, ldy, Y + (size_t)c1 * ldy + c0, ldy, d_W + off + c1, ldy, rr.count,
                                     m_pad - c1, width, T(-1), T(1), 0, 0, 0, 0, 0, ss);
         }
       }
-      rc = exchange_rows(d_V, ldy, rtab, c0, width, ss, KID_GATHER_V);           // every row of V_g on every rank
-      if (rc) return rc;
-      for (int q = 0; q < 2; ++q) {                        // Sigma[rows, :] -= V_g[rows] V_g^T: camera tile, own panel
-        const Rows& rr = ranges[q];
-        if (rr.count == 0) continue;
-        Scope sc(this, KID_DOWNDATE, ss);
-        if (sc.on) prof_work[KID_DOWNDATE] += 2.0 * rr.count * double(n) * (std::min(c1, m) - std::min(c0, m));
-        gemm<ROLE_DOWNDATE, false>(d_V + (size_t)rr.r0 * ldy + c0, ldy, d_V + c0, ldy, S() + (size_t)rr.r0 * ld, ld, rr.count,
-                                   npad_live, width, T(-1), T(1), 0, 0, 0, 0, 0, ss);
+      if (pend_g >= 0) {                                   // the downdate of the previous chunk, behind this chunk's solve
+        HIPCHK(hipStreamWaitEvent(stream_b, ev_gath[pend_g], 0));
+        downdate_chunk(pend_c0, pend_c1, stream_b);
+        pend_g = -1;
+      }
+      if (overlap) {
+        pend_g = gi; pend_c0 = c0; pend_c1 = c1;
+      } else {
+        // last chunk, everything on the main stream: gather (the staging buffers are free once the gather stream has
+        // drained), then its downdate behind every earlier one
+        if (side_busy) {
+          HIPCHK(hipEventRecord(ev_g, stream_g));
+          HIPCHK(hipStreamWaitEvent(stream, ev_g, 0));
+        }
+        rc = exchange_rows(d_V, ldy, rtab, c0, width, stream, KID_GATHER_V);
+        if (rc) return rc;
+        if (side_busy) {
+          HIPCHK(hipEventRecord(ev_b, stream_b));
+          HIPCHK(hipStreamWaitEvent(stream, ev_b, 0));
+        }
+        downdate_chunk(c0, c1, stream);
       }
     }
     HIPCHK(hipGetLastError());
@@ -1884,7 +1960,7 @@ struct Filter : FilterBase {
     int rc = sync_layout();
     if (rc) return -rc;
     k_linearity<T><<<(N + 127) / 128, 128, 0, stream>>>(mu(), S(), ld, d_pos, d_coding, N, d_cflag, d_Jy, d_Yxyz, 0);
-    if (sh_world > 1) {
+    if (exchanges()) {
       const ShardTab tab = feature_tab();
       int mx = 0;
       for (int g = 0; g < sh_world; ++g) mx = std::max(mx, tab.count[g]);

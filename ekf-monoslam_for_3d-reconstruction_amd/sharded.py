@@ -62,7 +62,7 @@ class TorchAllGather:
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.world, self.rank, self.device_index = world, rank, device_index
-        self.backend = dist.get_backend() if world > 1 else "none"
+        self.backend = dist.get_backend() if dist.is_initialized() else "none"
         self._views = {}
         self._streams = {}
         self.calls = 0
@@ -111,8 +111,10 @@ class TorchAllGather:
 
 
 def configure(flt, rank, world, device_index=0):
-    """Switch a VSlamFilter (every rank built it by the same calls) to sharded operation over torch.distributed."""
-    ag = TorchAllGather(world, rank, device_index) if world > 1 else None
+    """Switch a VSlamFilter (every rank built it by the same calls) to sharded operation over torch.distributed.
+    EKF_SHARD_FORCE_COLLECTIVE=1 keeps the exchanges at world 1 too (the collective path on one GPU, for profiling)."""
+    force = os.environ.get("EKF_SHARD_FORCE_COLLECTIVE", "0") not in ("", "0")
+    ag = TorchAllGather(world, rank, device_index) if (world > 1 or force) else None
     flt._allgather = ag                          # keeps the ctypes callback alive as long as the filter
     flt._check(flt._lib.ekf_shard_configure(flt._h, int(rank), int(world),
                                             ag.c_callback if ag else C.cast(None, ALLGATHER_FN), None))
