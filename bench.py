@@ -32,6 +32,16 @@ PEAK_F32_MFMA_TF = 157.3     # MI355X_MICROARCH.md: f32-input MFMA = vector peak
 SIGMA_Z_PX = 0.5              # pixel noise of the synthetic stream (the filter's R stays sigma_pixel^2 = 4)
 
 
+def csrc_sha():
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "ekf-monoslam_for_3d-reconstruction_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hpp", ".hip")):
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -41,6 +51,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-propagate-pass", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--cpu-full", action="store_true",
+                    help="also time ONE frame of the dense formulation on a single thread (minutes at N = 1000; for profiles/)")
     ap.add_argument("--pipeline", type=int, default=-1, help="EKF_OPT_PIPELINE (overlap chain with solve/downdate pieces)")
     ap.add_argument("--split-bf16", action="store_true",
                     help="EKF_OPT_SPLIT_BF16: downdate on the bf16 matrix pipe, fp32 operands split 3 x bf16 (NOT the default "
@@ -127,40 +139,73 @@ def run_steps(ring, d_z, d_idx, n_feat, first, count, bytes_per_frame):
         flt.update_device(d_z.data_ptr() + f * bytes_per_frame, d_idx.data_ptr(), n_feat, False)
 
 
-def cpu_baseline(cfg_name, n_feat, px0, zs, threads):
-    """Predict+update frames of the same workload in the reference's dense formulation
-    (oracle.DenseFilter: F Sigma F^T, H Sigma H^T, Sigma H^T S^-1, (I-KH) Sigma, Qc Sigma Qc^T as
-    dense products, vR.cpp:457-477, 598, 1268-1280, 1641) with sgemm/inverse from OpenBLAS."""
+def _oracle_pair(o, ocfg, n_feat, px0):
+    s = o.StructuredFilter(ocfg, np.float32)
+    s.dT = 1.0 / 30.0
+    for (u, v) in px0:
+        assert s.add_feature(u, v) == 1
+    d = o.DenseFilter(ocfg, np.float32)
+    d.dT = s.dT
+    d.mu, d.Sigma = s.mu.copy(), s.Sigma.copy()
+    d.features = [o.Feature(position_in_state=f.position_in_state) for f in s.features]
+    return s, d
+
+
+def cpu_baseline(cfg_name, n_feat, px0, zs, threads, full=False):
+    """Predict + update frames of the same workload on the host cores (a bounded sample, ~20 s in all):
+      dense   the reference's formulation (oracle.DenseFilter: F Sigma F^T, H Sigma H^T, Sigma H^T S^-1, (I - K H) Sigma,
+              Qc Sigma Qc^T as dense n^3 products, vR.cpp:457-477, 598, 1268-1280, 1641), sgemm / inverse from OpenBLAS
+      structured  the same update exploiting the identity blocks (O(n^2 m))
+    on all cores, and on ONE thread (the reference builds without OpenMP, mono-slam/CMakeLists.txt:3: single-thread SSE4
+    Eigen): the structured port is timed on one thread; one dense frame on one thread is ~3.5e12 flop at N = 1000
+    (over a minute), so by default it is ESTIMATED from the measured single-thread sgemm rate (flagged as such) and only
+    measured with --cpu-full.  /usr/include/eigen3 is probed: with Eigen on the box the reference's own expressions could
+    be compiled; without it (the case so far) this port is the baseline."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ekf_oracle as o
     from threadpoolctl import threadpool_info, threadpool_limits
     ocfg = o.Config.kinect()
+    idx = list(range(n_feat))
+    out = {"eigen3_on_box": os.path.isdir("/usr/include/eigen3") or os.path.isdir("/usr/local/include/eigen3")}
+
+    def timed(filt, max_frames, budget_s):
+        ts = []
+        end = time.perf_counter() + budget_s
+        for k in range(min(max_frames, len(zs))):
+            t0 = time.perf_counter()
+            filt.predict()
+            filt.update(zs[k].reshape(-1), idx)
+            ts.append(time.perf_counter() - t0)
+            if time.perf_counter() > end:
+                break
+        return float(np.median(ts)), len(ts)
+
     with threadpool_limits(limits=threads):
         used = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
-        s = o.StructuredFilter(ocfg, np.float32)
-        s.dT = 1.0 / 30.0
-        for (u, v) in px0:
-            assert s.add_feature(u, v) == 1
-        d = o.DenseFilter(ocfg, np.float32)
-        d.dT = s.dT
-        d.mu, d.Sigma = s.mu.copy(), s.Sigma.copy()
-        d.features = [o.Feature(position_in_state=f.position_in_state) for f in s.features]
-        idx = list(range(n_feat))
-        # a bounded sample: as many frames of the stream as fit ~10 s (at least 1, at most 20), median frame time
-        td, ts_ = [], []
-        budget = time.perf_counter() + 10.0
-        for k in range(min(20, len(zs))):
-            t0 = time.perf_counter()
-            d.predict()
-            d.update(zs[k].reshape(-1), idx)
-            td.append(time.perf_counter() - t0)
-            t0 = time.perf_counter()
-            s.predict()
-            s.update(zs[k].reshape(-1), idx)
-            ts_.append(time.perf_counter() - t0)
-            if time.perf_counter() > budget:
-                break
-    return float(np.median(td)), float(np.median(ts_)), used, len(td)
+        s, d = _oracle_pair(o, ocfg, n_feat, px0)
+        t_dense, n_dense = timed(d, 20, 8.0)
+        t_struct, n_struct = timed(s, 20, 3.0)
+    out.update({"dense_s": t_dense, "dense_frames": n_dense, "structured_s": t_struct, "threads": used})
+    with threadpool_limits(limits=1):
+        s1, d1 = _oracle_pair(o, ocfg, n_feat, px0)
+        t_struct1, n1 = timed(s1, 5, 6.0)
+        # single-thread sgemm rate on a 2048^3 product (the dense frame is n^3 sgemm work to > 95 %)
+        a = np.random.default_rng(0).standard_normal((2048, 2048)).astype(np.float32)
+        a @ a
+        t0 = time.perf_counter()
+        a @ a
+        rate = 2 * 2048.0 ** 3 / (time.perf_counter() - t0)
+        n = d1.n
+        m = 2 * n_feat
+        # predict 2 x 2n^3, S 2 m n^2 + 2 m^2 n, K 2 n^2 m + 2 n m^2 + ~2 m^3 (inverse), (I - K H) Sigma 2 n^2 m + 2 n^3, normalise 2 x 2n^3
+        dense_flop = 4.0 * n ** 3 + 2.0 * m * n * n + 2.0 * m * m * n + 2.0 * n * n * m + 2.0 * n * m * m + 2.0 * m ** 3 \
+            + 2.0 * n * n * m + 2.0 * n ** 3 + 4.0 * n ** 3
+        out.update({"structured_1thread_s": t_struct1, "sgemm_1thread_gflops": rate / 1e9,
+                    "dense_1thread_s_estimate": dense_flop / rate, "dense_flop_per_frame": dense_flop})
+        if full:
+            t_dense1, _ = timed(d1, 1, 1.0)
+            out["dense_1thread_s_measured"] = t_dense1
+    return out
 
 
 def launch_ranks(args):
@@ -284,13 +329,26 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
                              "--pipeline 0 runs one launch" % pieces)
                             if pieces > 1 or args.pipeline != 0 else "one launch per step"}
 
-    # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside bench.py)
-    pmc_path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-    pmc = json.load(open(pmc_path))["kernels"] if (n_feat == 1000 and os.path.exists(pmc_path)) else {}
+    # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside bench.py).  The
+    # counters belong to the kernel sources they were collected on: the file carries a fingerprint of csrc/, and
+    # `traffic` is reported only while it matches the sources of THIS run (else null, with the reason).
+    pmc, pmc_note = {}, None
+    for tag in ("r2", "r1"):
+        pmc_path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
+        if n_feat == 1000 and os.path.exists(pmc_path):
+            doc = json.load(open(pmc_path))
+            if doc.get("csrc_sha16") == csrc_sha():
+                pmc = doc["kernels"]
+                pmc_note = (f"profiles/{tag}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                            f"FETCH_SIZE x2), collected on these kernel sources (csrc sha {doc['csrc_sha16']})")
+            else:
+                pmc_note = (f"profiles/{tag}_pmc_traffic.json predates the kernel sources of this run "
+                            f"(csrc sha {doc.get('csrc_sha16')} != {csrc_sha()}): traffic not reported")
+            break
     dd_key = next((k for k in pmc if k.startswith("k_gemm_mfma<2, false")), None)     # ROLE 2 = downdate
-    if roofline and dd_key:
-        roofline["traffic"] = pmc[dd_key]["hbm_bytes_per_launch"]
-        roofline["traffic_source"] = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2)"
+    if roofline:
+        roofline["traffic"] = pmc[dd_key]["hbm_bytes_per_launch"] if dd_key else None
+        roofline["traffic_source"] = pmc_note
     result = {
         "metric": "EKF updates/sec at N features (state dim 14+6N)",
         "value": round(args.steps / elapsed, 2), "unit": "updates/s",
@@ -311,6 +369,30 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
     flt.close()                             # the secondary passes build their own maps
 
     if not args.no_propagate_pass:
+        # secondary figure: the step as a drop-in caller drives it (vR.cpp:868-875: update() reads every patch's h and
+        # the 2x2 St blocks that predict() left, and the matcher's z arrives from the host): per frame
+        # ekf_predict -> ekf_get_predictions (h, flags, 2x2 St blocks: D2H + one synchronisation) -> ekf_update with z and
+        # the index list from HOST memory (H2D).  Not `value`: the headline keeps inputs resident (bench contract).
+        flt5 = FilterRing(pkg, cfg, n_feat, px0, z, frames)
+        idx_h = np.arange(n_feat, dtype=np.int32)
+
+        def run_dropin(first, count):
+            for f in range(first, first + count):
+                f5 = flt5.at(f)
+                f5.predict()
+                f5.predictions()
+                f5.update(z[f].reshape(-1), idx_h)
+        run_dropin(0, args.warmup)
+        flt5.synchronize()
+        t0 = time.perf_counter()
+        run_dropin(args.warmup, args.steps)
+        flt5.synchronize()
+        t1 = time.perf_counter()
+        result["secondary_dropin_step"] = {
+            "what": "predict + ekf_get_predictions (h, flags, 2x2 St blocks to the host) + ekf_update from host z / indices",
+            "value": round(args.steps / (t1 - t0), 2), "unit": "updates/s", "ms_per_step": round(1e3 * (t1 - t0) / args.steps, 4)}
+        flt5.close()
+
         # secondary workload: M = 32 measured features per frame, the reference's real
         # operating point (conf_sim.cfg:24-25) -- the dense contractions shrink to rank 64 and the step
         # becomes HBM-bound (W pass + rank-64 downdate stream Sigma)
@@ -391,13 +473,26 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
 
     if not args.no_cpu_baseline:
         threads = args.cpu_threads or len(os.sched_getaffinity(0))
-        t_dense, t_struct, used, nfr = cpu_baseline("kinect", n_feat, px0, z, threads)
-        result["cpu_baseline"] = {"value": round(1.0 / t_dense, 4), "unit": "updates/s", "cores": used,
-                                  "kind": "port",
-                                  "sample": f"median of {nfr} frame(s) (predict+update, ~10 s of host time) of the same N={n_feat}, M=N workload in the "
-                                            "reference's dense n^3 formulation, numpy/OpenBLAS sgemm",
-                                  "seconds_per_update": round(t_dense, 3),
-                                  "structured_port_updates_per_s": round(1.0 / t_struct, 3)}
+        cb = cpu_baseline("kinect", n_feat, px0, z, threads, args.cpu_full)
+        d1 = cb.get("dense_1thread_s_measured")
+        result["cpu_baseline"] = {
+            "value": round(1.0 / cb["dense_s"], 4), "unit": "updates/s", "cores": cb["threads"], "kind": "port",
+            "sample": f"median of {cb['dense_frames']} frame(s) (predict+update, ~8 s of host time) of the same N={n_feat}, M=N "
+                      "workload in the reference's dense n^3 formulation, numpy/OpenBLAS sgemm, every host core",
+            "seconds_per_update": round(cb["dense_s"], 3),
+            "structured_port_updates_per_s": round(1.0 / cb["structured_s"], 3),
+            "one_thread": {
+                "why": "the reference builds without OpenMP (mono-slam/CMakeLists.txt:3): its Eigen path is single-threaded",
+                "structured_port_updates_per_s": round(1.0 / cb["structured_1thread_s"], 4),
+                "dense_port_updates_per_s": round(1.0 / (d1 or cb["dense_1thread_s_estimate"]), 5),
+                "dense_port_is": "measured (1 frame)" if d1 else
+                                 f"ESTIMATED: {cb['dense_flop_per_frame']:.3g} flop per frame / the measured single-thread sgemm rate "
+                                 f"({cb['sgemm_1thread_gflops']:.1f} GFLOP/s); --cpu-full measures it",
+            },
+            "eigen3_on_box": cb["eigen3_on_box"],
+            "eigen_note": "no /usr/include/eigen3 on the box: the reference's own Eigen expressions cannot be compiled here"
+                          if not cb["eigen3_on_box"] else "Eigen headers present on the box",
+        }
     return result
 
 

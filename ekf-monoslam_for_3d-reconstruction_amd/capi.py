@@ -75,6 +75,8 @@ _PROTOS = {
     "ekf_export_points": (C.c_int, [_P, _P, C.c_int]),
     "ekf_get_search_ellipses": (C.c_int, [_P, C.c_int, _P]),
     "ekf_ransac_1point": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, _P, _P, C.POINTER(C.c_int)]),
+    "ekf_update_two_stage": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_uint, C.c_double, C.c_double, _P, _P,
+                                       C.POINTER(C.c_int)]),
     "ekf_innovation_covariance": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "ekf_get_gain": (C.c_int, [_P, _P]),
     "ekf_last_measurement_rows": (C.c_int, [_P]),

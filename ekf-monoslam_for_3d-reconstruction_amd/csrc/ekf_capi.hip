@@ -95,6 +95,8 @@ struct FilterBase {
   virtual int rescue(const void*, const void*, const int*, int, double, unsigned char*) = 0;
   virtual int search_ellipses(int, int*) = 0;
   virtual int ransac(const void*, const int*, int, double, int*, unsigned char*, int*) = 0;
+  virtual int update_two_stage(const void*, const int*, int, int, unsigned int, double, double, unsigned char*,
+                               unsigned char*, int*) = 0;
   virtual int set_frame(const unsigned char*, int, int, int) = 0;
   virtual int set_patch(int, const unsigned char*) = 0;
   virtual int get_patch(int, int, unsigned char*) = 0;
@@ -174,6 +176,7 @@ struct Filter : FilterBase {
   hipEvent_t ev_gath[8] = {}, ev_g = nullptr;
   int opt_chain_mask = 0;                               // 1: chain of chunks >= 1 on the reserved CUs only (measured slower: the trailing updates want more CUs)
   int solve64_off = 0, solve6464_off = 0, tri64_off = 0, tri64_count = 0;
+  double opt_feature_noise = 0.0;                       // EKF_OPT_FEATURE_NOISE: variance added to every feature state per predict
   int opt_split_bf16 = 0;                               // EKF_OPT_SPLIT_BF16: downdate on the bf16 matrix pipe, 3 x bf16 per operand
   __bf16* d_Vs[3] = {nullptr, nullptr, nullptr};
   int last_nchunks = 1, last_cend[8] = {};
@@ -458,6 +461,7 @@ struct Filter : FilterBase {
       case EKF_OPT_PROFILE: resolve_profile(); opt_profile = v; return EKF_OK;
       case EKF_OPT_PIPELINE: opt_pipeline = (v < 0) ? -1 : v; return EKF_OK;
       case EKF_OPT_SPLIT_BF16: opt_split_bf16 = v ? 1 : 0; return EKF_OK;
+      case EKF_OPT_FEATURE_NOISE: opt_feature_noise = (v > 0) ? 1e-12 * v : 0.0; return EKF_OK;
       default: FAIL(EKF_ERR_ARG, "unknown option");
     }
   }
@@ -754,6 +758,8 @@ struct Filter : FilterBase {
       Scope sc(this, KID_PROPAGATE_STRIPS);
       k_strip_congruence<T, 13><<<(2 * n + 255) / 256, 256, 0, stream>>>(S(), ld, n, 0, d_scr + SCR_FT, d_scr + SCR_Q);
     }
+    if (opt_feature_noise > 0.0 && n > camera_dim)
+      k_inflate_diagonal<T><<<(n - camera_dim + 255) / 256, 256, 0, stream>>>(S(), ld, camera_dim, n, T(opt_feature_noise));
     HIPCHK(hipGetLastError());
     have_update = false;
     int rcm = launch_measure();
@@ -1521,6 +1527,109 @@ struct Filter : FilterBase {
     return EKF_OK;
   }
 
+  // ---- f1: the whole RANSAC branch of VSlamFilter::update (vR.cpp:964-1130 + 1245-1284) in one call -------------
+  // glibc's rand() (random_r TYPE_3: additive feedback r[i] = r[i-3] + r[i-31], seeded by the Lehmer generator
+  // 16807 x mod 2^31 - 1, 310 outputs discarded, result >> 1): the reference draws its hypotheses with
+  // srand(time(NULL)) / rand() (vR.cpp:970, 989), so a given seed reproduces its draw sequence on a glibc platform.
+  struct GlibcRand {
+    std::vector<unsigned int> st;
+    explicit GlibcRand(unsigned int seed) {
+      if (seed == 0) seed = 1;
+      st.assign(34, 0);
+      st[0] = seed;
+      for (int i = 1; i < 31; ++i) {
+        long long v = (16807LL * (int)st[i - 1]) % 2147483647LL;
+        if (v < 0) v += 2147483647LL;
+        st[i] = (unsigned int)v;
+      }
+      for (int i = 31; i < 34; ++i) st[i] = st[i - 31];
+      for (int i = 34; i < 344; ++i) st.push_back(st[i - 31] + st[i - 3]);
+    }
+    int next() {
+      const size_t i = st.size();
+      st.push_back(st[i - 31] + st[i - 3]);
+      return (int)(st[i] >> 1);
+    }
+  };
+
+  int update_two_stage(const void* z_, const int* idx, int M, int plane, unsigned int seed, double thr, double chi2,
+                       unsigned char* is_li, unsigned char* is_hi, int* hyp_drawn) override {
+    HIPCHK(hipSetDevice(device));
+    if (sh_on) FAIL(EKF_ERR_UNSUPPORTED, "ekf_update_two_stage is not available on a sharded filter");
+    if (M < 0 || M > N) FAIL(EKF_ERR_ARG, "M out of range");
+    if (!have_meas) FAIL(EKF_ERR_STATE, "ekf_update_two_stage needs the h / H of ekf_predict");
+    const T* z = static_cast<const T*>(z_);
+    std::vector<unsigned char> li(M, 0), hi(M, 0);
+    int drawn = 0;
+    if (M > 0) {
+      std::vector<int> counts(M);
+      int best = 0;
+      int rc = ransac(z, idx, M, thr, counts.data(), nullptr, &best);        // every hypothesis, one device pass
+      if (rc) return rc;
+      int sel = best;
+      if (seed != 0) {
+        // the reference's loop (vR.cpp:986-1034): draw without replacement, adapt the number of hypotheses to the best
+        // inlier ratio seen; the low-innovation set is that of the LAST hypothesis drawn (its flags are overwritten
+        // on every draw, :1022)
+        GlibcRand rng(seed);
+        std::vector<int> list(M);
+        for (int k = 0; k < M; ++k) list[k] = k;
+        int nhyp = 10000, num_zli = 0;
+        const float p = 0.99f;
+        for (int i = 0; i < nhyp && !list.empty(); ++i) {
+          const int posr = rng.next() % (int)list.size();
+          sel = list[posr];
+          list.erase(list.begin() + posr);
+          ++drawn;
+          if (counts[sel] > num_zli) {
+            num_zli = counts[sel];
+            nhyp = (int)(std::log(1 - p) / (std::log(1 - (num_zli / (M + 0.0f)))));   // :1030 (-> 0 when all are inliers)
+          }
+        }
+      } else {
+        drawn = M;
+      }
+      HIPCHK(hipMemcpy2DAsync(li.data(), 1, d_rmask + sel, (size_t)M, 1, M, hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+    }
+    T cam_before[7];
+    HIPCHK(hipMemcpyAsync(cam_before, mu(), sizeof(cam_before), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    std::vector<T> zl, zr;
+    std::vector<int> il, ir, kr;
+    for (int k = 0; k < M; ++k) {
+      auto& zz = li[k] ? zl : zr;
+      (li[k] ? il : ir).push_back(idx[k]);
+      if (!li[k]) kr.push_back(k);
+      zz.push_back(z[2 * k]);
+      zz.push_back(z[2 * k + 1]);
+    }
+    if (!il.empty()) {                                           // low-innovation update (vR.cpp:1036-1064): no plane rows
+      int rc = update(zl.data(), il.data(), (int)il.size(), 0, false);
+      if (rc) return rc;
+    }
+    std::vector<T> zh;
+    std::vector<int> ih;
+    if (!ir.empty()) {                                           // high-innovation rescue (vR.cpp:1066-1117)
+      std::vector<unsigned char> g(ir.size(), 0);
+      int rc = rescue(cam_before, zr.data(), ir.data(), (int)ir.size(), chi2, g.data());
+      if (rc) return rc;
+      for (size_t t = 0; t < ir.size(); ++t)
+        if (g[t]) { hi[kr[t]] = 1; ih.push_back(ir[t]); zh.push_back(zr[2 * t]); zh.push_back(zr[2 * t + 1]); }
+    }
+    if (!ih.empty() || plane) {                                  // second update incl. the plane rows (vR.cpp:1245-1284)
+      if (ih.empty()) {                                          // plane rows only: h / H of no feature are needed
+        have_meas = true;
+      }
+      int rc = update(zh.data(), ih.data(), (int)ih.size(), plane, false);
+      if (rc) return rc;
+    }
+    if (is_li) memcpy(is_li, li.data(), M);
+    if (is_hi) memcpy(is_hi, hi.data(), M);
+    if (hyp_drawn) *hyp_drawn = drawn;
+    return EKF_OK;
+  }
+
   // ---- multi-GPU row-panel sharding ------------------------------------------------
   // One process per GPU; every rank holds the same feature list and runs every resize operation, rank g OWNS the
   // contiguous features [sh_fb[g], sh_fb[g+1]) and keeps valid: the rows of Sigma / W / V of those features (all
@@ -1706,6 +1815,8 @@ struct Filter : FilterBase {
       Scope sc(this, KID_PROPAGATE_STRIPS);
       k_strip_congruence<T, 13><<<(2 * n + 255) / 256, 256, 0, stream>>>(S(), ld, n, 0, d_scr + SCR_FT, d_scr + SCR_Q);
     }
+    if (opt_feature_noise > 0.0 && n > camera_dim)
+      k_inflate_diagonal<T><<<(n - camera_dim + 255) / 256, 256, 0, stream>>>(S(), ld, camera_dim, n, T(opt_feature_noise));
     const int f0 = own_f0(), f1 = own_f1();
     if (f1 > f0) {
       Scope sc(this, KID_MEASURE);
@@ -2179,6 +2290,12 @@ int ekf_ransac_1point(ekf_filter* f, const void* z, const int* idx, int M, doubl
                       unsigned char* inl, int* best) {
   IMPL_OR_ARG(f);
   return f->impl->ransac(z, idx, M, thr, counts, inl, best);
+}
+int ekf_update_two_stage(ekf_filter* f, const void* z, const int* idx, int M, int plane, unsigned int seed,
+                         double thr, double chi2, unsigned char* is_li, unsigned char* is_hi, int* drawn) {
+  IMPL_OR_ARG(f);
+  if (M > 0 && (!z || !idx)) return EKF_ERR_ARG;
+  return f->impl->update_two_stage(z, idx, M, plane, seed, thr, chi2, is_li, is_hi, drawn);
 }
 int ekf_shard_configure(ekf_filter* f, int rank, int world, ekf_allgather_fn fn, void* ctx) {
   IMPL_OR_ARG(f);

@@ -808,6 +808,13 @@ __global__ void k_check_invariants(const T* __restrict__ S, int ld, int n, int n
   }
 }
 
+// EKF_OPT_FEATURE_NOISE (opt-in): Sigma[i][i] += delta for the feature states (i >= camera_dim), once per predict.
+template <typename T>
+__global__ void k_inflate_diagonal(T* __restrict__ S, int ld, int first, int n, T delta) {
+  const int i = first + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) S[(size_t)i * ld + i] += delta;
+}
+
 template <typename T>
 __global__ void k_fill(T* __restrict__ p, size_t count, T v) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)

@@ -258,6 +258,21 @@ class VSlamFilter:
                                                 self._ptr(counts), self._ptr(inl), C.byref(best)))
         return counts, best.value, inl.astype(bool)
 
+    def updateTwoStage(self, z, indices, plane_constraint: Optional[bool] = None, seed: int = 0,
+                       ransac_threshold: Optional[float] = None, chi2_threshold: float = 1.0):
+        """The RANSAC branch of update() (vR.cpp:964-1130 + 1245-1284) in one call: (is_li (M,), is_hi (M,), draws)."""
+        plane = bool(self._cfg.forsePlane) if plane_constraint is None else bool(plane_constraint)
+        z = np.ascontiguousarray(z, self.dtype).reshape(-1)
+        idx = np.ascontiguousarray(indices, np.int32)
+        thr = 2.0 * self._cfg.sigma_pixel if ransac_threshold is None else float(ransac_threshold)
+        li = np.zeros(idx.size, np.uint8)
+        hi = np.zeros(idx.size, np.uint8)
+        drawn = C.c_int()
+        self._check(self._lib.ekf_update_two_stage(self._h, self._ptr(z), self._ptr(idx), idx.size, int(plane),
+                                                   int(seed), thr, float(chi2_threshold), self._ptr(li), self._ptr(hi),
+                                                   C.byref(drawn)))
+        return li.astype(bool), hi.astype(bool), drawn.value
+
     def getGain(self):
         m = self._lib.ekf_last_measurement_rows(self._h)
         n = self.stateDim()

@@ -84,7 +84,15 @@ enum ekf_option {
    * maps runs on the bf16 matrix pipe with each fp32 operand split exactly into three bf16 values and the six
    * products above 2^-25 |a||b| accumulated in fp32 (csrc/ekf_split.hpp): fp32-class accuracy, not bit-equal
    * to the fp32 instruction.  fp32 filters only. */
-  EKF_OPT_SPLIT_BF16 = 4
+  EKF_OPT_SPLIT_BF16 = 4,
+  /* 0 (default: the reference's model -- the map is static, features carry no process noise).  v > 0: every
+   * predict adds v x 1e-12 to the variance of every feature state (Sigma[i][i], i >= camera_dim): the "stabilising
+   * noise" of EKF-SLAM practice.  With every feature measured in every frame an fp32 covariance otherwise loses
+   * positivity after a few thousand updates (rounding of the large, unobservable scale mode leaks into the
+   * well-observed directions until one eigenvalue crosses zero, and a negative eigenvalue then grows);
+   * tools/drift_probe.py, profiles/r2_positivity_*.txt.  v = 10000 (1e-8 per frame) keeps the N = 400 map positive
+   * through 4000 frames where the default stops at frame 1489 (v = 1000 does not).  Any dtype. */
+  EKF_OPT_FEATURE_NOISE = 5
 };
 
 /* Fills `cfg` with the reference defaults (ConfigVSLAM.cpp:27-47, camModel.hpp:22-31). */
@@ -186,6 +194,25 @@ int ekf_ransac_1point(ekf_filter* f, const void* z, const int* indices, int M, d
  * features keep the new h / H, so a following ekf_update over the rescued ones uses them (:1119-1130). */
 int ekf_rescue_high_innovation(ekf_filter* f, const void* cam_before, const void* z, const int* indices,
                                int M, double chi2_threshold, unsigned char* is_hi);
+
+/* The RANSAC branch of VSlamFilter::update in ONE call (vR.cpp:964-1130 + 1245-1284), for the matched features
+ * `indices` (strictly ascending, M of them) with pixels z:
+ *   1. every 1-point hypothesis is evaluated on the device (as ekf_ransac_1point, threshold `ransac_threshold`;
+ *      the reference uses 2 * sigma_pixel, :968);
+ *   2. seed == 0: the low-innovation set is that of the BEST hypothesis (most inliers, lowest index on ties) -- the
+ *      deterministic form.  seed != 0: the reference's own loop is replayed on those counts -- hypotheses drawn
+ *      without replacement with glibc's srand(seed) / rand() sequence (the reference seeds with time(NULL), :970),
+ *      nhyp adapted as (int)(log(1 - 0.99) / log(1 - best_count / M)) (:1030), and the low-innovation set is that of
+ *      the LAST hypothesis drawn (the reference overwrites the flags on every draw, :1022);
+ *   3. EKF update with the low-innovation inliers, no plane rows (:1036-1064);
+ *   4. the remaining matched features are re-linearised at (camera pose before step 3, features after it) and
+ *      gated by (h - z)^T S_hi^-1 (h - z) <= chi2_threshold with S_hi = H Sigma H^T (:1066-1117; the reference uses 1);
+ *   5. second EKF update with the rescued features and, if plane_constraint, the forsePlane rows (:1245-1284).
+ * Outputs (any may be NULL): is_low_innovation / is_high_innovation, one byte per listed feature;
+ * hypotheses_drawn = draws of the replayed loop (M in the deterministic form).  Needs ekf_predict. */
+int ekf_update_two_stage(ekf_filter* f, const void* z, const int* indices, int M, int plane_constraint,
+                         unsigned int seed, double ransac_threshold, double chi2_threshold,
+                         unsigned char* is_low_innovation, unsigned char* is_high_innovation, int* hypotheses_drawn);
 
 /* ---- image side: what sits between predict() and the EKF update in the reference ----
  * captureNewFrame's image (vR.cpp:234-245) AFTER the node's resize / grayscale: 8-bit, single channel,

@@ -73,6 +73,14 @@ class VSlamFilterHip {
                                      hi.data()));
     return hi;
   }
+  // update() as the reference runs it (USE_RANSAC, vR.cpp:964-1130 + 1245-1284): RANSAC -> low-innovation update ->
+  // rescue -> second update (+ forsePlane rows) in one call.  seed = 0: best hypothesis; else srand(seed) replay.
+  void updateTwoStage(const std::vector<float>& z, const std::vector<int>& indices, bool forsePlane, unsigned int seed,
+                      float sigma_pixel, std::vector<unsigned char>& isInLi, std::vector<unsigned char>& isInHi) {
+    isInLi.assign(indices.size(), 0); isInHi.assign(indices.size(), 0);
+    check(ekf_update_two_stage(h_, z.data(), indices.data(), (int)indices.size(), forsePlane ? 1 : 0, seed,
+                               2.0 * sigma_pixel, 1.0, isInLi.data(), isInHi.data(), nullptr));
+  }
   // ---- image side: captureNewFrame's frame, Patch::findMatch for every visible feature -------------
   // gray: 8-bit single-channel frame after the node's resize (image_width x image_height of the config)
   void setFrame(const unsigned char* gray, int width, int height, int stride) {

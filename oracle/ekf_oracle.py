@@ -788,6 +788,82 @@ def rescue_high_innovation(filt, mu_before, z, indices, threshold=1.0, return_ch
     return (out, chi2) if return_chi2 else out
 
 
+class GlibcRand:
+    """glibc's srand(seed) / rand() (random_r TYPE_3: r[i] = r[i-3] + r[i-31] mod 2^32 over a table seeded by the
+    Lehmer generator 16807 x mod (2^31 - 1); the first 310 outputs are discarded; rand() = r >> 1).  The reference
+    draws its RANSAC hypotheses with srand(time(NULL)) / rand() (vR.cpp:970, 989)."""
+
+    def __init__(self, seed):
+        seed = int(seed) & 0xffffffff or 1
+        r = [seed]
+        for i in range(1, 31):
+            prev = r[i - 1] - (1 << 32) if r[i - 1] >= (1 << 31) else r[i - 1]      # as int32
+            v = int(np.fmod(16807 * prev, 2147483647))                              # C remainder: sign of the dividend
+            if v < 0:
+                v += 2147483647
+            r.append(v)
+        for i in range(31, 34):
+            r.append(r[i - 31])
+        for i in range(34, 344):
+            r.append((r[i - 31] + r[i - 3]) & 0xffffffff)
+        self.r = r
+
+    def rand(self):
+        r = self.r
+        v = (r[-31] + r[-3]) & 0xffffffff
+        r.append(v)
+        return v >> 1
+
+
+def update_two_stage(filt, z, indices, plane=False, seed=0, threshold=None, chi2_threshold=1.0):
+    """The RANSAC branch of VSlamFilter::update (vR.cpp:964-1130 + 1245-1284) on the matched features `indices`.
+    seed = 0: low-innovation set of the best hypothesis (lowest index on ties); seed != 0: the reference's loop --
+    draws without replacement from srand(seed) / rand(), adaptive nhyp (:1030), flags of the LAST draw (:1022).
+    Returns (is_li, is_hi, hypotheses drawn)."""
+    T = filt.T
+    indices = list(indices)
+    M = len(indices)
+    z = np.asarray(z, T).reshape(M, 2)
+    li = np.zeros(M, bool)
+    hi = np.zeros(M, bool)
+    drawn = 0
+    if M:
+        counts, mask = ransac_1point(filt, z, indices, threshold)
+        sel = int(np.argmax(counts))
+        drawn = M
+        if seed:
+            rng = GlibcRand(seed)
+            lst = list(range(M))
+            nhyp, num_zli, i = 10000, 0, 0
+            p = np.float32(0.99)
+            drawn = 0
+            while i < nhyp and lst:
+                sel = lst.pop(rng.rand() % len(lst))                                   # :989-991
+                drawn += 1
+                if counts[sel] > num_zli:
+                    num_zli = int(counts[sel])
+                    with np.errstate(divide="ignore"):
+                        ratio = np.float32(num_zli) / np.float32(M)
+                        den = np.log(np.float32(1) - ratio)
+                        val = np.log(np.float32(1) - p) / den                          # :1030
+                    nhyp = int(val) if np.isfinite(val) else 0
+                i += 1
+        li = mask[sel].copy()
+    mu_before = filt.mu.copy()
+    if li.any():
+        sel_i = [indices[k] for k in range(M) if li[k]]
+        filt.update(z[li].reshape(-1), sel_i, plane=False)                             # :1036-1064
+    rest_k = [k for k in range(M) if not li[k]]
+    if rest_k:
+        flags = rescue_high_innovation(filt, mu_before, z[rest_k], [indices[k] for k in rest_k], chi2_threshold)
+        for t, k in enumerate(rest_k):
+            hi[k] = bool(flags[t])
+    if hi.any() or plane:
+        sel_i = [indices[k] for k in range(M) if hi[k]]
+        filt.update(z[hi].reshape(-1), sel_i, plane=plane)                             # :1245-1284
+    return li, hi, drawn
+
+
 # --------------------------------------------------------------------------
 # structured filter: identical arithmetic, identity blocks exploited
 # --------------------------------------------------------------------------

@@ -324,6 +324,86 @@ def test_n200_full_1000_frame_stream_with_resync():
     assert bound("end Sigma vs free-running fp64 oracle (1000 frames)", relf(S, S_end), 5e-3)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("seed,plane", [(0, False), (7, False), (12345, True), (99, False)])
+def test_update_two_stage_composite_matches_oracle(dtype, seed, plane):
+    """ekf_update_two_stage = the USE_RANSAC branch of VSlamFilter::update in one call (vR.cpp:964-1130 + 1245-1284):
+    hypotheses, the reference's draw loop replayed from glibc's srand(seed) / rand() with the adaptive nhyp (:1030)
+    (seed 0: best hypothesis), low-innovation update, rescue, second update with the plane rows."""
+    ref, g = make_pair(30, dtype)
+    ref.predict()
+    g.predict()
+    vis = ref.visible_indices()
+    z = o.synthetic_measurements(ref, vis, sigma=1.0).reshape(-1, 2)
+    z[4] += 7.0                                        # outside 2 sigma_px, maybe inside the chi2 gate
+    z[13] += 60.0                                      # gross mismatches: never rescued
+    z[21] -= 45.0
+    # gate between the two kinds of outliers so that both outcomes of the rescue occur (the reference's gate of 1 is
+    # very tight: S_hi carries no pixel noise)
+    import copy
+    probe = copy.deepcopy(ref)
+    li0, _, _ = o.update_two_stage(probe, z, vis, plane=False, seed=seed)
+    rest = [vis[k] for k in range(len(vis)) if not li0[k]]
+    gate = 1.0
+    if rest:
+        _, chi2 = o.rescue_high_innovation(probe, ref.mu.copy(), z[~li0], rest, return_chi2=True)
+        c = np.sort(np.asarray(chi2, np.float64))
+        gate = float(np.sqrt(c[0] * c[-1])) if len(c) > 1 and c[0] > 0 else 1.0
+    li_ref, hi_ref, drawn_ref = o.update_two_stage(ref, z, vis, plane=plane, seed=seed, chi2_threshold=gate)
+    li, hi, drawn = g.updateTwoStage(z, vis, plane_constraint=plane, seed=seed, chi2_threshold=gate)
+    assert drawn == drawn_ref and (seed == 0 or drawn < len(vis))          # the adaptive count stops the loop early
+    assert list(li) == list(li_ref) and list(hi) == list(hi_ref)
+    if seed == 0:                                      # (a replayed loop may end on an outlier's hypothesis: the reference's quirk, :1022)
+        assert not li[13] and not li[21] and li.sum() >= len(vis) - 4
+    mu, S = gpu_state(g)
+    t = TOL[dtype]
+    assert bound("mu, ref.mu", relf(mu, ref.mu), t["mu"] * 10) and bound("S, ref.Sigma", relf(S, ref.Sigma), t["S"] * 5)
+
+
+def test_feature_noise_option_keeps_a_long_all_measured_run_positive():
+    """EKF_OPT_FEATURE_NOISE (opt-in, off by default = the reference's static-map model).  With every feature measured
+    in every frame the fp32 covariance loses positivity after a map-size dependent number of updates (N = 400: one
+    eigenvalue crosses zero near frame 900, the Cholesky of S fails at frame 1489; tools/drift_probe.py) and the filter
+    stops with EKF_ERR_NUMERIC.  1e-8 of variance per feature state and predict keeps Sigma positive (to rounding)."""
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from ekf_monoslam_amd import synthetic
+    cfg = pkg.kinect_config()
+    ref, g = make_pair(12, np.float64)                        # the option does what it says, and nothing when it is off
+    g.set_option(5, 2500000)                                  # 2.5e-6 per predict
+    d0 = np.diag(g.getFullSigma()).copy()
+    ref.predict()
+    g.predict()
+    d1 = np.diag(g.getFullSigma())
+    dref = np.diag(ref.Sigma)
+    assert np.allclose(d1[14:] - dref[14:], 2.5e-6, rtol=1e-6) and np.allclose(d1[:14], dref[:14], rtol=1e-12)
+    N, frames = 400, 1700
+    px0, zs = synthetic.measurement_stream(cfg, N, frames, sigma_px=0.5)
+    idx = np.arange(N, dtype=np.int32)
+    stopped = {}
+    for noise in (0, 10000):
+        f = pkg.VSlamFilter(cfg, capacity_features=N)
+        f.setDt(1.0 / 30.0)
+        for (u, v) in px0:
+            assert f.addFeature((u, v)) == 1
+        f.set_option(5, noise)
+        try:
+            for k in range(frames):
+                f.predict()
+                f.update(zs[k].reshape(-1), idx)
+                if k % 100 == 99:
+                    f.synchronize()
+            f.synchronize()
+            w = np.linalg.eigvalsh(f.getFullSigma().astype(np.float64))
+            stopped[noise] = (None, float(w[0]), float(w[-1]))
+        except pkg.EkfError as e:
+            assert e.status == 5                              # EKF_ERR_NUMERIC
+            stopped[noise] = (k, None, None)
+    assert stopped[0][0] is not None and 1300 <= stopped[0][0] <= 1700, stopped      # the default stops (frame 1489)
+    k, lo, hi = stopped[10000]
+    assert k is None and lo > -1e-9 * hi, stopped                                    # with the option: positive to rounding
+
+
 def test_error_paths():
     from __graft_entry__ import load_package
     pkg = load_package()

@@ -164,3 +164,15 @@ def test_camera_dim_13_variant_has_no_scale_element():
     z = o.synthetic_measurements(f, f.visible_indices())
     f.update(z)
     assert np.all(np.isfinite(f.Sigma))
+
+
+def test_glibc_rand_matches_the_c_library():
+    """The RANSAC draws of the reference are srand(time(NULL)) / rand() (vR.cpp:970, 989): the oracle's (and the
+    library's) replay generator must BE glibc's rand() -- checked against the C library of this machine."""
+    import ctypes
+    libc = ctypes.CDLL("libc.so.6")
+    for seed in (1, 7, 42, 123456789, 2 ** 31 + 5, 2 ** 32 - 1):
+        libc.srand(ctypes.c_uint(seed))
+        want = [libc.rand() for _ in range(400)]
+        g = o.GlibcRand(seed)
+        assert [g.rand() for _ in range(400)] == want

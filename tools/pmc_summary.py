@@ -9,11 +9,24 @@ Counters are KB per dispatch.  On gfx950 FETCH_SIZE reports half of the bytes of
 import collections
 import csv
 import glob
+import hashlib
 import json
+import os
 import re
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def csrc_sha():
+    """Fingerprint of the kernel sources the counters were collected on (bench.py drops `traffic` when it differs)."""
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "ekf-monoslam_for_3d-reconstruction_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hpp", ".hip")):
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def short(k):
@@ -35,6 +48,6 @@ for k, v in out.items():
 json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 5 --warmup 2 "
                    "--no-cpu-baseline` (N=M=1000, fp32, default options: pipelined solve/downdate pieces); counters are KB per "
                    "dispatch; read side doubled per MI355X_MICROARCH.md (FETCH_SIZE reports 1/2 of wide coalesced reads on gfx950)",
-           "kernels": out}, open(dst, "w"), indent=1)
+           "csrc_sha16": csrc_sha(), "kernels": out}, open(dst, "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:10]:
     print(f"{k:40s} {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB/launch")
