@@ -266,6 +266,9 @@ int ekf_get_sigma_block(ekf_filter* f, void* out, int r0, int c0, int rows, int 
 int ekf_set_sigma_block(ekf_filter* f, const void* in, int r0, int c0, int rows, int cols);
 /* Covariance_Parameter (vR.cpp:841-866): trace of Sigma[0:7,0:7]. */
 int ekf_covariance_parameter(ekf_filter* f, double* out);
+/* Diagnostic (EKF_FLOW_TRACE=1 in the environment of ekf_create): per task of the last update's persistent dataflow
+ * launch 4 words -- fetched, inputs ready, stored (100 MHz ticks), workgroup | type << 32.  tools/flow_trace.py. */
+int ekf_debug_flow_trace(ekf_filter* f, unsigned long long* out, int max_tasks, int* ntasks);
 /* Invariants of the device-resident covariance, evaluated on the device (no n^2 copy): max |Sigma| outside the live
  * n x n inside the padded buffer (the tile kernels rely on exact zeros there), max |Sigma[i][j] - Sigma[j][i]| and
  * max |Sigma[i][j]| over the live block (the reference never symmetrises, vR.cpp:1279; this implementation keeps

@@ -744,6 +744,32 @@ def test_fused_wupdate_launch_is_bit_identical(monkeypatch):
         assert np.array_equal(mu, outs[0][0]) and np.array_equal(S, outs[0][1])
 
 
+def test_dataflow_launch_is_bit_identical(monkeypatch):
+    """EKF_FLOW=1 (opt-in, csrc/ekf_flow.hpp): every solve / W-update / downdate tile of an update in ONE persistent
+    launch with device-side dependencies (release / acquire hand-offs between workgroups, bounded waits).  Same tiles,
+    same arithmetic per tile: mu and Sigma must equal the launch-per-phase path to the last bit, over several frames."""
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from ekf_monoslam_amd import synthetic
+    cfg = pkg.kinect_config()
+    n_feat = 640                                             # 10 block steps, chunks 3 / 6 / 10, 465 lower tiles >= 256 CUs
+    px0, z = synthetic.measurement_stream(cfg, n_feat, 4, sigma_px=0.5)
+    idx = np.arange(n_feat, dtype=np.int32)
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("EKF_FLOW", mode)                 # read when the filter is created
+        f = pkg.VSlamFilter(cfg, capacity_features=n_feat)
+        f.setDt(1.0 / 30.0)
+        for (u, v) in px0:
+            assert f.addFeature((u, v)) == 1
+        for k in range(3):
+            f.predict()
+            f.update(z[k].reshape(-1), idx)
+        f.synchronize()                                      # raises if a wait inside the launch timed out
+        outs.append((f.getFullState(), f.getFullSigma()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_profile_reports_time_and_work_of_the_downdate():
     """EKF_OPT_PROFILE = 1 times the downdate launches with HIP events; ekf_profile_work reports their algorithmic
     flop: n^2 x the measured columns (symmetric half) plus, for the launch that carries its chunk's W update,
