@@ -376,6 +376,92 @@ def test_hip_shard_full_size_matches_plain_path(world, n_feat):
     assert seen.all()
 
 
+def _gpu_n4000_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from ekf_monoslam_amd import sharded, synthetic
+    N = 4000
+    cfg = pkg.kinect_config()
+    px0, z = synthetic.measurement_stream(cfg, N, 2, sigma_px=0.5)
+    flt = pkg.VSlamFilter(cfg, capacity_features=N + 64, dtype=np.float32)
+    flt.setDt(1.0 / 30.0)
+    for (u, v) in px0:
+        assert flt.addFeature((u, v)) == 1
+    sharded.configure(flt, rank, world)
+    rng = np.random.default_rng(1236)
+    drop = sorted(rng.choice(N, size=40, replace=False).tolist())       # 1 % out, the same number in (SURVEY 8d, configs[4])
+    add = [(float(rng.uniform(20, 300)), float(rng.uniform(20, 220))) for _ in range(40)]
+    idx = np.arange(N, dtype=np.int32)
+    flt.predict()
+    flt.update(z[0].reshape(-1), idx)
+    flt.removeFeatures(drop)
+    for (u, v) in add:
+        assert flt.addFeature((u, v)) == 1
+    keep = np.setdiff1d(np.arange(N), drop)
+    flt.predict()
+    h, vis, rem, _ = flt.predictions()
+    sel = np.nonzero(vis[:len(keep)])[0].astype(np.int32)                # the surviving features of the stream that are visible
+    flt.update(z[1][keep][sel].reshape(-1), sel)
+    flt.synchronize()
+    info = sharded.shard_info(flt)
+    pad, asym, big = flt.checkInvariants()
+    rows = np.r_[0:14, info.row_begin:min(info.row_begin + 200, info.row_end), max(info.row_begin, info.row_end - 200):info.row_end]
+    blocks = [flt.getSigmaBlock(int(r), 0, 1, flt.stateDim()) for r in rows[::7]]
+    out[rank] = (flt.getFullState(), rows[::7], np.concatenate(blocks), (info.f_begin, info.f_end), pad, flt.numOfFeatures())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_hip_shard_n4000_resize_two_ranks_match_plain_path():
+    """BASELINE configs[4] at FULL size (N = 4000, n = 24 014, fp32, 63 block steps) under sharding: two ranks sharing the GPU
+    (collectives through gloo), one frame, 1 % of the features removed and as many added (descending removal order,
+    additions at the end, vR.cpp:1296-1315), a second frame on a measured subset -- every rank's rows against the plain
+    single-GPU path on the same calls."""
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from ekf_monoslam_amd import synthetic
+    N = 4000
+    cfg = pkg.kinect_config()
+    px0, z = synthetic.measurement_stream(cfg, N, 2, sigma_px=0.5)
+    flt = pkg.VSlamFilter(cfg, capacity_features=N + 64, dtype=np.float32)
+    flt.setDt(1.0 / 30.0)
+    for (u, v) in px0:
+        assert flt.addFeature((u, v)) == 1
+    rng = np.random.default_rng(1236)
+    drop = sorted(rng.choice(N, size=40, replace=False).tolist())
+    add = [(float(rng.uniform(20, 300)), float(rng.uniform(20, 220))) for _ in range(40)]
+    idx = np.arange(N, dtype=np.int32)
+    flt.predict()
+    flt.update(z[0].reshape(-1), idx)
+    flt.removeFeatures(drop)
+    for (u, v) in add:
+        assert flt.addFeature((u, v)) == 1
+    keep = np.setdiff1d(np.arange(N), drop)
+    flt.predict()
+    h, vis, rem, _ = flt.predictions()
+    sel = np.nonzero(vis[:len(keep)])[0].astype(np.int32)
+    flt.update(z[1][keep][sel].reshape(-1), sel)
+    flt.synchronize()
+    mu_p = flt.getFullState()
+    n = flt.stateDim()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gpu_n4000_worker, args=(2, free_port(), out), nprocs=2, join=True)
+    ranges = []
+    for rank in range(2):
+        mu, rows, S_rows, frange, pad, nfeat = out[rank]
+        assert nfeat == N and mu.shape == (n,) and np.all(np.isfinite(mu)) and pad == 0.0
+        assert bound("rank mu vs plain path", relf(mu, mu_p), 2e-5)
+        ref_rows = np.concatenate([flt.getSigmaBlock(int(r), 0, 1, n) for r in rows])
+        assert bound("rank Sigma rows vs plain path", relf(S_rows, ref_rows), 5e-4)
+        ranges.append(frange)
+    assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == N
+
+
 @pytest.mark.gpu
 def test_shard_argument_checks():
     from __graft_entry__ import load_package

@@ -1,0 +1,64 @@
+// How much of the symmetric launch is its last, partially filled round?  Same kernel, same K, the first `ntiles` tiles of the
+// list on 512 (448) workgroups: time per tile for exact multiples of the slot count against 1128.  (debug harness)
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../ekf-monoslam_for_3d-reconstruction_amd/csrc/ekf_dense.hpp"
+using namespace ekf;
+int main() {
+  const int n = 6016, ldy = 2048, ld = 6144;
+  float *V, *S;
+  hipMalloc(&V, (size_t)(n + 128) * ldy * 4); hipMalloc(&S, (size_t)(n + 128) * ld * 4);
+  std::vector<float> h((size_t)(n + 128) * ldy); for (auto& x : h) x = (rand() % 2001 - 1000) * 1e-3f;
+  hipMemcpy(V, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  hipMemset(S, 0, (size_t)(n + 128) * ld * 4);
+  std::vector<int> tm; const int nt128 = n / 128, SB = 8, ns = (nt128 + SB - 1) / SB;
+  for (int si = 0; si < ns; ++si) for (int sj = 0; sj <= si; ++sj)
+    for (int i = si * SB; i < std::min(nt128, (si + 1) * SB); ++i)
+      for (int j = sj * SB; j < std::min(nt128, (sj + 1) * SB); ++j) if (j <= i) { tm.push_back(i); tm.push_back(j); }
+  const int nt = (int)tm.size() / 2;
+  int* dtm; hipMalloc(&dtm, tm.size() * 4); hipMemcpy(dtm, tm.data(), tm.size() * 4, hipMemcpyHostToDevice);
+  int* counters; hipMalloc(&counters, 65536 * 4); hipMemset(counters, 0, 65536 * 4);
+  hipEvent_t ea, eb; hipEventCreate(&ea); hipEventCreate(&eb);
+  int cn = 0;
+  for (int K : {512, 1024}) for (int wgs : {512, 448, 256}) for (int ntiles : {wgs, 2 * wgs, nt, 3 * wgs > nt ? nt : 3 * wgs}) {
+    float best = 1e9;
+    for (int pass = 0; pass < 3; ++pass) {
+      const int reps = 20;
+      hipDeviceSynchronize();
+      hipEventRecord(ea);
+      for (int r = 0; r < reps; ++r) {
+        GemmArgs a{V, ldy, V, ldy, S, ld, K, -1.0, 1.0, 2, 0, 0, 0, 0, dtm, ntiles, counters + (cn++ % 60000), 0, 0, 1};
+        k_gemm_mfma<ROLE_DOWNDATE, false><<<std::min(ntiles, wgs), 256>>>(a);
+      }
+      hipEventRecord(eb); hipEventSynchronize(eb);
+      float ms; hipEventElapsedTime(&ms, ea, eb); best = std::min(best, ms / reps);
+    }
+    printf("K=%4d wgs=%3d tiles=%4d (%.2f rounds): %.1f us  %.3f us/tile/slot-round  %.1f TF\n", K, wgs, ntiles, (double)ntiles / wgs,
+           best * 1e3, best * 1e3 / ((double)ntiles / wgs), 2.0 * ntiles * 128 * 128 * K / best / 1e9);
+  }
+  // ablation: what do the C tile read (beta = 1 -> 0) and the mirror stores (tri 2 -> 1) cost?
+  for (int K : {384, 640, 1024}) for (int wgs : {512, 448}) {
+    for (int var = 0; var < 4; ++var) {
+      const double beta = (var & 1) ? 0.0 : 1.0;
+      const int tri = (var & 2) ? 1 : 2;
+      float best = 1e9;
+      for (int pass = 0; pass < 3; ++pass) {
+        const int reps = 20;
+        hipDeviceSynchronize();
+        hipEventRecord(ea);
+        for (int r = 0; r < reps; ++r) {
+          GemmArgs a{V, ldy, V, ldy, S, ld, K, -1.0, beta, tri, 0, 0, 0, 0, dtm, nt, counters + (cn++ % 60000), 0, 0, 1};
+          k_gemm_mfma<ROLE_DOWNDATE, false><<<std::min(nt, wgs), 256>>>(a);
+        }
+        hipEventRecord(eb); hipEventSynchronize(eb);
+        float ms; hipEventElapsedTime(&ms, ea, eb); best = std::min(best, ms / reps);
+      }
+      printf("ablation K=%4d wgs=%3d  C read %s  mirror %s: %.1f us  %.1f TF\n", K, wgs, beta ? "yes" : "no ", tri == 2 ? "yes" : "no ",
+             best * 1e3, 2.0 * nt * 128 * 128 * K / best / 1e9);
+    }
+  }
+  return 0;
+}
