@@ -71,14 +71,11 @@ def build_filter(pkg, cfg, n_feat, px0):
 
 
 def segment_frames(n_feat):
-    """Frames one map may run with EVERY feature measured in EVERY frame before its fp32 covariance stops being
-    positive (the reference's formulation -- single precision, no square root, no feature process noise -- loses
-    positivity there: N = 200 after 5363 frames, 500 after 1241, 1000 after 783 on this stream, the fp64 filter
-    never; tools/long_run.py).  Longer runs continue on a map started afresh from the stream's current pixels: the
-    work per step is the same."""
-    if n_feat <= 200:
-        return 3000
-    return max(100, int(450.0 * (1000.0 / n_feat) ** 1.2))
+    """Frames one map runs before the stream continues on a map started afresh from its current pixels (the work per
+    step is the same).  With EVERY feature measured in EVERY frame the fp32 covariance stays positive to rounding for
+    as long as it was followed (N = 200: 12000 frames, 400: 6000, 1000: 3000, 2000: 2500, 4000: 1200;
+    tools/drift_probe.py, tools/long_run.py, profiles/r2_drift_after_fix.txt); the ring only bounds what was verified."""
+    return 3000 if n_feat <= 1000 else 1200
 
 
 class FilterRing:

@@ -457,35 +457,18 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmArgs g) {   // two wor
     }
   }
   const int h = lane >> 5, l31 = lane & 31;
-  // accumulators start at (beta/alpha) C, so the epilogue is a pure store: the C tile is read
-  // once, up front, under the first operand loads (alpha is never 0)
-  // (the beta test is hoisted out of the element loop: a per-element "load or zero" select makes
-  // hipcc branch around every load and wait for each one)
+  // The accumulators start at zero and C enters once, in the epilogue (C' = beta C + alpha acc, one rounding at
+  // the magnitude of C).  Starting them at (beta / alpha) C instead -- the C tile read up front, the epilogue a pure
+  // store -- rounds every one of the K partial sums at the magnitude of C: the products below half an ulp of C are
+  // dropped one by one, and the covariance downdate then loses positivity after ~1700 all-measured frames at N = 200
+  // where this form holds it (tools/drift_hybrid.py, profiles/r2_drift_hybrid.txt).
   f32x16 acc[MI][NJ];
-  if (beta != 0.f) {
-    const float cscale = beta / alpha;
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const float* Cp = C + (size_t)(bi * TM + wr * (TM / 2) + i * 32 + 4 * h) * ldc + bj * TN + wc * (TN / 2) + j * 32 + l31;
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = Cp[(size_t)((e & 3) + 8 * (e >> 2)) * ldc];
-      }
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] *= cscale;
-  } else {
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  }
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   constexpr int PBL = BT ? 4 : PB;             // B float4 loads per lane
   f32x4 ra[PA], rb[4];
   auto load_tile = [&](int k0) {
@@ -572,7 +555,16 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmArgs g) {   // two wor
   // epilogue: acc reg e of lane -> row (e&3) + 8*(e>>2) + 4*h, col l31 of the 32x32 tile
   const bool mirror = (TM == TN) && (tri == 2) && (grow0 >= gcol0 + TM);
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+  for (int i = 0; i < MI; ++i) {
+    f32x16 cin[NJ];
+    if (beta != 0.f) {                         // the C loads of one 32-row band go out together, ahead of their use
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const float* Cp = C + (size_t)(bi * TM + wr * (TM / 2) + i * 32 + 4 * h) * ldc + bj * TN + wc * (TN / 2) + j * 32 + l31;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) cin[j][e] = beta * Cp[(size_t)((e & 3) + 8 * (e >> 2)) * ldc];
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int rbase = bi * TM + wr * (TM / 2) + i * 32;
@@ -581,7 +573,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmArgs g) {   // two wor
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int r = rbase + (e & 3) + 8 * (e >> 2) + 4 * h;
-        const float x = alpha * acc[i][j][e];
+        const float x = (beta != 0.f) ? __builtin_fmaf(alpha, acc[i][j][e], cin[j][e]) : alpha * acc[i][j][e];
         v[e] = x;
         C[(size_t)r * ldc + c] = x;
       }
@@ -595,6 +587,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmArgs g) {   // two wor
         }
       }
     }
+  }
 #ifdef EKF_GEMM_STAMP
   EKF_PHASE_STAMP(ph_t4);
   ph_sum[0] += ph_t1 - ph_t0; ph_sum[1] += ph_t2 - ph_t1; ph_sum[2] += ph_t3 - ph_t2; ph_sum[3] += ph_t4 - ph_t3;
@@ -673,17 +666,9 @@ __global__ void __launch_bounds__(256) k_gemm_mfma_f64(GemmArgs g) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (beta != 0.0) {
-        const double cs = beta / alpha;
-        const double* Cp = C + (size_t)(bi * TS + wr * 32 + i * 16 + kq) * ldc + bj * TS + wc * 32 + j * 16 + l15;
+    for (int j = 0; j < 2; ++j)                  // C enters in the epilogue: one rounding at its magnitude (see k_gemm_mfma)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i][j][e] = cs * Cp[(size_t)(4 * e) * ldc];
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0;
-      }
-    }
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0;
   f64x2 ra[2], rb[2];
   auto load_tile = [&](int k0) {
 #pragma unroll
@@ -749,7 +734,7 @@ __global__ void __launch_bounds__(256) k_gemm_mfma_f64(GemmArgs g) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = bi * TS + wr * 32 + i * 16 + 4 * e + kq;
-        const double x = alpha * acc[i][j][e];
+        const double x = (beta != 0.0) ? __builtin_fma(alpha, acc[i][j][e], beta * C[(size_t)r * ldc + c]) : alpha * acc[i][j][e];
         C[(size_t)r * ldc + c] = x;
         if (mirror) C[(size_t)(c + g.col_off - g.row_off) * ldc + (r + g.row_off - g.col_off)] = x;
       }

@@ -129,31 +129,13 @@ __global__ void __launch_bounds__(256, 2) k_gemm_flow(FlowArgs g) {
           bslot[p] = qk * TN + ((4 * cq + p) ^ qk);
         }
       }
-      f32x16 acc[MI][NJ];
-      if (has_beta) {
-        const float cscale = 1.f / alpha;          // beta = 1
+      f32x16 acc[MI][NJ];                          // C enters in the epilogue, as in k_gemm_mfma (bit-identical to it)
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            const float* Cp = C + (size_t)(wr * (TM / 2) + i * 32 + 4 * h) * ldc + wc * (TN / 2) + j * 32 + l31;
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = Cp[(size_t)((e & 3) + 8 * (e >> 2)) * ldc];
-          }
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] *= cscale;
-      } else {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-      }
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
       f32x4 ra[PA], rb[4];
       auto load_tile = [&](int k0) {
 #pragma unroll
@@ -230,7 +212,16 @@ __global__ void __launch_bounds__(256, 2) k_gemm_flow(FlowArgs g) {
       const bool mirror = (type == FLOW_DOWNDATE) && (tk.bi > tk.bj);
       float* Ct = g.Sigma + (size_t)(tk.bj * TN) * g.ld + (size_t)tk.bi * TM;       // origin of the mirrored tile (J, I)
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+      for (int i = 0; i < MI; ++i) {
+        f32x16 cin[NJ];
+        if (has_beta) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const float* Cp = C + (size_t)(wr * (TM / 2) + i * 32 + 4 * h) * ldc + wc * (TN / 2) + j * 32 + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) cin[j][e] = Cp[(size_t)((e & 3) + 8 * (e >> 2)) * ldc];
+          }
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const int rbase = wr * (TM / 2) + i * 32;
@@ -239,7 +230,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_flow(FlowArgs g) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int r = rbase + (e & 3) + 8 * (e >> 2) + 4 * h;
-            const float x = alpha * acc[i][j][e];
+            const float x = has_beta ? __builtin_fmaf(alpha, acc[i][j][e], cin[j][e]) : alpha * acc[i][j][e];
             v[e] = x;
             C[(size_t)r * ldc + c] = x;
           }
@@ -251,6 +242,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_flow(FlowArgs g) {
             }
           }
         }
+      }
     }
     // publish: every storing wave drains, the workgroup meets, lane 0 releases and counts
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

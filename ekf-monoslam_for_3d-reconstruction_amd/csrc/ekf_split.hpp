@@ -96,11 +96,9 @@ __global__ void __launch_bounds__(256, 2) k_syrk_bf16x3(SplitArgs g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float* Cp = C + (size_t)(bi * T + wr * 64 + i * 32 + 4 * h) * ldc + bj * T + wc * 64 + j * 32 + l31;
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = -Cp[(size_t)((e & 3) + 8 * (e >> 2)) * ldc];   // acc = -C; C' = -acc
-      }
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;       // C' = C - acc in the epilogue: one rounding at |C|
     f32x4 rg[2][3][2];
     auto load_regs = [&](int k0) {
 #pragma unroll
@@ -163,7 +161,7 @@ __global__ void __launch_bounds__(256, 2) k_syrk_bf16x3(SplitArgs g) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int r = rbase + (e & 3) + 8 * (e >> 2) + 4 * h;
-            const float x = -acc[i][j][e];
+            const float x = C[(size_t)r * ldc + c] - acc[i][j][e];
             if (r >= c) {
               C[(size_t)r * ldc + c] = x;
               C[(size_t)c * ldc + r] = x;
@@ -174,7 +172,7 @@ __global__ void __launch_bounds__(256, 2) k_syrk_bf16x3(SplitArgs g) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int r = rbase + (e & 3) + 8 * (e >> 2) + 4 * h;
-          v[e] = -acc[i][j][e];
+          v[e] = C[(size_t)r * ldc + c] - acc[i][j][e];
           C[(size_t)r * ldc + c] = v[e];
         }
         if (mirror) {

@@ -17,6 +17,8 @@ g = pkg.VSlamFilter(cfg, capacity_features=N, dtype=dt)
 g.setDt(1 / 30.0)
 if os.environ.get("EKF_NOISE"):
     g.set_option(5, int(os.environ["EKF_NOISE"]))      # EKF_OPT_FEATURE_NOISE, units of 1e-12 per predict
+if os.environ.get("EKF_MFMA"):
+    g.set_option(1, int(os.environ["EKF_MFMA"]))       # EKF_OPT_USE_MFMA: 0 = plain VALU tiles
 for (u, v) in px0:
     g.addFeature((u, v))
 idx = np.arange(N, dtype=np.int32)
