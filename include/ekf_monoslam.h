@@ -87,11 +87,9 @@ enum ekf_option {
   EKF_OPT_SPLIT_BF16 = 4,
   /* 0 (default: the reference's model -- the map is static, features carry no process noise).  v > 0: every
    * predict adds v x 1e-12 to the variance of every feature state (Sigma[i][i], i >= camera_dim): the "stabilising
-   * noise" of EKF-SLAM practice.  With every feature measured in every frame an fp32 covariance otherwise loses
-   * positivity after a few thousand updates (rounding of the large, unobservable scale mode leaks into the
-   * well-observed directions until one eigenvalue crosses zero, and a negative eigenvalue then grows);
-   * tools/drift_probe.py, profiles/r2_positivity_*.txt.  v = 10000 (1e-8 per frame) keeps the N = 400 map positive
-   * through 4000 frames where the default stops at frame 1489 (v = 1000 does not).  Any dtype. */
+   * noise" of EKF-SLAM practice, for callers who want it.  The fp32 filter does not need it to stay positive: with
+   * every feature measured in every frame Sigma stays positive to rounding over every run followed so far (N = 200:
+   * 12000 frames, 1000: 3000, 4000: 1200; profiles/r2_drift_after_fix.txt).  Any dtype. */
   EKF_OPT_FEATURE_NOISE = 5
 };
 
