@@ -180,6 +180,12 @@ struct Filter : FilterBase {
   hipEvent_t ev_gath[8] = {}, ev_g = nullptr;
   int opt_chain_mask = 0;                               // 1: chain of chunks >= 1 on the reserved CUs only (measured slower: the trailing updates want more CUs)
   int solve64_off = 0, solve6464_off = 0, tri64_off = 0, tri64_count = 0;
+  int trih_off = 0, trih_count = 0;                      // the 128 x 128 list with its last opt_split_tail tiles as 64 x 128 halves
+  int opt_gemm_waves = 4, opt_gemm_waves_where = 7;      // EKF_GEMM_WAVES=8: 128 x 128 tile GEMMs with eight waves (where: 1 downdate, 2 W update, 4 solve)
+  // EKF_SPLIT_TAIL (-1: 1.5 tiles per CU, at most a third of the list) / EKF_SPLIT_WHERE (1: downdate on the main stream,
+  // 2: on the side stream).  Measured at N = 1000: 384 halves on the last downdate 1.348 -> 1.329 ms; on the CU-masked side
+  // stream no gain; eight-wave workgroups (EKF_GEMM_WAVES=8) 3-5 % faster per launch alone, nothing in the step.
+  int opt_split_tail = -1, opt_split_where = 1;
   double opt_feature_noise = 0.0;                       // EKF_OPT_FEATURE_NOISE: variance added to every feature state per predict
   int opt_split_bf16 = 0;                               // EKF_OPT_SPLIT_BF16: downdate on the bf16 matrix pipe, 3 x bf16 per operand
   __bf16* d_Vs[3] = {nullptr, nullptr, nullptr};
@@ -396,6 +402,10 @@ struct Filter : FilterBase {
       if (const char* e = getenv("EKF_XCD_QUEUES")) opt_xcd_queues = atoi(e);
       if (const char* e = getenv("EKF_PANEL_DIRECT")) opt_panel_direct = atoi(e);
       if (const char* e = getenv("EKF_FLOW")) opt_flow = atoi(e);
+      if (const char* e = getenv("EKF_GEMM_WAVES")) opt_gemm_waves = atoi(e);
+      if (const char* e = getenv("EKF_GEMM_WAVES_WHERE")) opt_gemm_waves_where = atoi(e);
+      if (const char* e = getenv("EKF_SPLIT_TAIL")) opt_split_tail = atoi(e);
+      if (const char* e = getenv("EKF_SPLIT_WHERE")) opt_split_where = atoi(e);
       if (const char* e = getenv("EKF_CHUNKS")) {           // tuning knob: chunk ends in block steps
         for (const char* q = e; *q && env_nchunks < 8;) {
           env_chunks[env_nchunks++] = atoi(q);
@@ -860,6 +870,13 @@ struct Filter : FilterBase {
     }
     if constexpr (kIsF32) {
       if (opt_mfma) {
+        if constexpr (TM == 128 && TN == 128 && (ROLE == ROLE_DOWNDATE || ROLE == ROLE_WUPDATE || ROLE == ROLE_SOLVE)) {
+          if (opt_gemm_waves == 8 && (ROLE != ROLE_SOLVE || (opt_gemm_waves_where & 4)) &&
+              (ROLE != ROLE_WUPDATE || (opt_gemm_waves_where & 2))) {
+            k_gemm_mfma<ROLE, BT, TM, TN, 8><<<grid, 512, 0, st>>>(g);
+            return;
+          }
+        }
         k_gemm_mfma<ROLE, BT, TM, TN><<<grid, 256, 0, st>>>(g);
         return;
       }
@@ -922,6 +939,14 @@ struct Filter : FilterBase {
             for (int j = sj * SB; j < std::min(nt64, (sj + 1) * SB); ++j)
               if (j <= i) { tm.push_back(i); tm.push_back(j); }
       tri64_count = ((int)tm.size() - tri64_off) / 2;
+    }
+    trih_off = (int)tm.size();
+    {
+      const int ns_ = (opt_split_tail < 0) ? std::min(3 * num_cus / 2, tri_count / 3) : std::min(opt_split_tail, tri_count);
+      for (int t = 0; t < tri_count - ns_; ++t) { tm.push_back(tm[2 * t]); tm.push_back(tm[2 * t + 1]); }
+      for (int t = tri_count - ns_; t < tri_count; ++t)
+        for (int h = 0; h < 2; ++h) { tm.push_back((2 * tm[2 * t] + h) | kHalfTile); tm.push_back(tm[2 * t + 1]); }
+      trih_count = ((int)tm.size() - trih_off) / 2;
     }
     HIPCHK(hipStreamSynchronize(stream));
     HIPCHK(hipStreamSynchronize(stream_b));
@@ -1375,11 +1400,13 @@ struct Filter : FilterBase {
           }
           const int nr2 = (npad_live + nb) / 128, n2 = nr2 * ((m_pad - c1) / 128);
           GemmArgs g{d_V + c0, ldy, d_V + c0, ldy, S(), ld, width, -1.0, 1.0, 2, 0, 0, 0, 0,
-                     d_tilemap, n2 + tri_count, d_counters + counter_next, 0, 0, 1,
+                     (opt_split_where & 2) ? d_tilemap + trih_off : d_tilemap, n2 + ((opt_split_where & 2) ? trih_count : tri_count),
+                     d_counters + counter_next, 0, 0, 1,
                      Y + (size_t)c1 * ldy + c0, ldy, d_W + c1, ldy, n2, nr2, opt_xcd_queues};
           counter_next += 8;
           const int wgs = 2 * (num_cus - reserved_cus);
-          k_gemm_mfma<ROLE_DOWNDATE, false><<<std::min(g.ntiles, wgs), 256, 0, ss>>>(g);
+          if (opt_gemm_waves == 8) k_gemm_mfma<ROLE_DOWNDATE, false, 128, 128, 8><<<std::min(g.ntiles, wgs), 512, 0, ss>>>(g);
+          else k_gemm_mfma<ROLE_DOWNDATE, false><<<std::min(g.ntiles, wgs), 256, 0, ss>>>(g);
           HIPCHK(hipEventRecord(ev_wu, stream_b));
         }
       } else if (!split_done) {
@@ -1388,6 +1415,9 @@ struct Filter : FilterBase {
         if (kIsF32 && opt_mfma && tri_count < num_cus)    // small map: 64 x 64 tiles, or most of the chip idles
           gemm<ROLE_DOWNDATE, false, 64, 64>(d_V + c0, ldy, d_V + c0, ldy, S(), ld, npad_live, npad_live, width, T(-1), T(1),
                                              2, 0, 0, 0, 0, ss, d_tilemap + tri64_off, tri64_count);
+        else if (opt_split_where & (ss == stream_b ? 2 : 1))
+          gemm<ROLE_DOWNDATE, false>(d_V + c0, ldy, d_V + c0, ldy, S(), ld, npad_live, npad_live, width, T(-1), T(1), 2, 0,
+                                     0, 0, 0, ss, d_tilemap + trih_off, trih_count);
         else
           gemm<ROLE_DOWNDATE, false>(d_V + c0, ldy, d_V + c0, ldy, S(), ld, npad_live, npad_live, width, T(-1), T(1), 2, 0,
                                      0, 0, 0, ss, d_tilemap, tri_count);

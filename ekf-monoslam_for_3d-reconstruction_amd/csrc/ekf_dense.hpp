@@ -10,6 +10,7 @@
 // All pads are multiples of the GEMM tile, and everything outside the live region is kept
 // zero, so the tile kernels carry no edge guards.
 #pragma once
+#include <type_traits>
 #include "ekf_math.hpp"
 
 namespace ekf {
@@ -251,6 +252,7 @@ struct GemmArgs {
   int xcd_queues;
 };
 constexpr int kSecondProduct = 0x10000;         // flag on bj for a tile of the second product
+constexpr int kHalfTile = 0x20000;              // flag on bi: 64-row half tile, bi & 0xffff in 64-row units (k_gemm_mfma, downdate)
 
 // Next tile of this workgroup: plain 2-D grid (one tile, then done) or the work queue.
 __device__ __forceinline__ bool gemm_next_tile(const GemmArgs& g, int* s_tile, int& iter, int& bi, int& bj) {
@@ -386,12 +388,18 @@ __device__ unsigned long long ekf_phase_buf[8 * 1024];   // fetch, prologue, K l
 #define EKF_PHASE_STAMP(var) do { } while (0)
 #endif
 
-template <int ROLE, bool BT, int TM = 128, int TN = 128>
-__global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmArgs g) {   // two workgroups per CU: <= 256 registers per lane
+template <int ROLE, bool BT, int TM = 128, int TN = 128, int NW = 4>
+__global__ void __launch_bounds__(64 * NW, NW / 2) k_gemm_mfma(GemmArgs g) {   // two workgroups per CU: NW / 2 waves per SIMD
   // TM x TN output tile (64 or 128 each), 4 waves as 2 x 2, each wave (TM/2) x (TN/2) = MI x NJ
   // accumulators of 32x32.  The small shapes exist for the latency-bound launches (chain tiles, tail of
   // the triangular solve): same flop, 2-4x the workgroups.
-  constexpr int BK = 32, NQ = BK / 4, MI = TM / 64, NJ = TN / 64, PA = TM / 32, PB = TN / 32;
+  // NW = 4 waves as 2 x 2 (each (TM/2) x (TN/2)) or NW = 8 waves as 2 x 4 (each (TM/2) x (TN/4); NT mode, TN = 128):
+  // four waves per SIMD instead of two to hide the barrier / LDS / global latency of each other.
+  constexpr int NT = 64 * NW, WC = NW / 2, BK = 32, NQ = BK / 4, NJ = TN / (32 * WC), PB = TN * 8 / NT;
+  static_assert(NW == 4 || (NW == 8 && TN == 128), "eight waves: 128 columns");
+  // a queued downdate launch may carry HALF tiles (64 x 128, kHalfTile on bi, bi then in 64-row units) at the end of
+  // its list: the last jobs of the slower workgroups are half as long, and the launch ends more evenly
+  constexpr bool SPLIT = (ROLE == ROLE_DOWNDATE) && !BT && TM == 128 && TN == 128;
   static_assert((TM == 64 || TM == 128) && (TN == 64 || TN == 128), "tile shape");
   const float* A = static_cast<const float*>(g.A);
   const float* B0 = static_cast<const float*>(g.B);
@@ -404,7 +412,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmArgs g) {   // two wor
   constexpr int STAGE = NQ * (TM + TN);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WC, wc = wave % WC;
   if (ROLE == ROLE_PANEL || ROLE == ROLE_TRAILING) __builtin_amdgcn_s_setprio(2);   // part of the serial chain
   if (g.stagger && g.tile_map && blockIdx.x >= gridDim.x / 2)
     for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
@@ -420,26 +428,28 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmArgs g) {   // two wor
   EKF_PHASE_STAMP(ph_t0);
   while (gemm_next_tile(g, &s_tile, iter, bi, bj)) {
   EKF_PHASE_STAMP(ph_t1);
+  auto tile_body = [&](auto tm_tag) {
+  constexpr int TMb = decltype(tm_tag)::value, MI = TMb / 64, PA = TMb * 8 / NT;
   const bool second = DUAL && (bj & kSecondProduct);
   if (DUAL) bj &= kSecondProduct - 1;
   const float* B = second ? static_cast<const float*>(g.B2) : B0;
   float* C = second ? static_cast<float*>(g.C2) : C0;
   const int ldb = second ? g.ldb2 : g.ldb, ldc = second ? g.ldc2 : g.ldc;
   const int tri = second ? 0 : g.tri;
-  const int grow0 = g.row_off + bi * TM, gcol0 = g.col_off + bj * TN;
-  if (tri && grow0 + TM <= gcol0) continue;
-  if (g.zrow && grow0 >= g.zrow && gcol0 >= g.zcol_end) continue;
+  const int grow0 = g.row_off + bi * TMb, gcol0 = g.col_off + bj * TN;
+  if (tri && grow0 + TMb <= gcol0) return;
+  if (g.zrow && grow0 >= g.zrow && gcol0 >= g.zcol_end) return;
   const int K = g.ktri ? min(g.K, (bj + g.ktile_off + 1) * TN) : g.K;
-  // A staging: TM*8 float4 per tile, PA per lane; 8 consecutive lanes cover 128 B of a row
+  // A staging: TMb*8 float4 per tile, PA per lane; 8 consecutive lanes cover 128 B of a row
   const float* Ag[PA];
   const float* Bg[4];
   int aslot[PA], bslot[4];
 #pragma unroll
   for (int p = 0; p < PA; ++p) {
-    const int idx = tid + 256 * p;
+    const int idx = tid + NT * p;
     const int row = idx >> 3, q = idx & 7;
-    Ag[p] = A + (size_t)(bi * TM + row) * lda + q * 4;
-    aslot[p] = q * TM + (row ^ q);
+    Ag[p] = A + (size_t)(bi * TMb + row) * lda + q * 4;
+    aslot[p] = q * TMb + (row ^ q);
   }
   // NN mode: lane owns k-quad qk and column quad cq: rows 4qk+p (p < 4), 4 columns; TN = 64 uses lanes < 128
   const int qk = tid / (TN / 4), cq = tid % (TN / 4);
@@ -447,7 +457,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmArgs g) {   // two wor
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     if (!BT) {
-      const int idx = tid + 256 * p;
+      const int idx = tid + NT * p;
       const int row = idx >> 3, q = idx & 7;
       Bg[p] = (p < PB) ? B + (size_t)(bj * TN + row) * ldb + q * 4 : B;
       bslot[p] = q * TN + (row ^ q);
@@ -480,7 +490,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmArgs g) {   // two wor
   };
   auto store_tile = [&](int stage) {
     f32x4* As = lds + stage * STAGE;
-    f32x4* Bs = As + NQ * TM;
+    f32x4* Bs = As + NQ * TMb;
 #pragma unroll
     for (int p = 0; p < PA; ++p) As[aslot[p]] = ra[p];
     if (!BT) {
@@ -504,16 +514,16 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmArgs g) {   // two wor
   f32x4 fa[2][MI], fb[2][NJ];
   auto read_frag = [&](int stage_, int s, int buf) {
     const f32x4* As = lds + stage_ * STAGE;
-    const f32x4* Bs = As + NQ * TM;
+    const f32x4* Bs = As + NQ * TMb;
     const int q = 2 * s + h;
 #pragma unroll
     for (int t = 0; t < MI; ++t) {
-      const int ar = wr * (TM / 2) + t * 32 + l31;
-      fa[buf][t] = As[q * TM + (ar ^ q)];
+      const int ar = wr * (TMb / 2) + t * 32 + l31;
+      fa[buf][t] = As[q * TMb + (ar ^ q)];
     }
 #pragma unroll
     for (int t = 0; t < NJ; ++t) {
-      const int br = wc * (TN / 2) + t * 32 + l31;
+      const int br = wc * (TN / WC) + t * 32 + l31;
       fb[buf][t] = Bs[q * TN + (br ^ q)];
     }
   };
@@ -553,22 +563,22 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmArgs g) {   // two wor
   }
   EKF_PHASE_STAMP(ph_t3);
   // epilogue: acc reg e of lane -> row (e&3) + 8*(e>>2) + 4*h, col l31 of the 32x32 tile
-  const bool mirror = (TM == TN) && (tri == 2) && (grow0 >= gcol0 + TM);
+  const bool mirror = (TMb == TN || SPLIT) && (tri == 2) && (grow0 >= gcol0 + TN);
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     f32x16 cin[NJ];
     if (beta != 0.f) {                         // the C loads of one 32-row band go out together, ahead of their use
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const float* Cp = C + (size_t)(bi * TM + wr * (TM / 2) + i * 32 + 4 * h) * ldc + bj * TN + wc * (TN / 2) + j * 32 + l31;
+        const float* Cp = C + (size_t)(bi * TMb + wr * (TMb / 2) + i * 32 + 4 * h) * ldc + bj * TN + wc * (TN / WC) + j * 32 + l31;
 #pragma unroll
         for (int e = 0; e < 16; ++e) cin[j][e] = beta * Cp[(size_t)((e & 3) + 8 * (e >> 2)) * ldc];
       }
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int rbase = bi * TM + wr * (TM / 2) + i * 32;
-      const int c = bj * TN + wc * (TN / 2) + j * 32 + l31;
+      const int rbase = bi * TMb + wr * (TMb / 2) + i * 32;
+      const int c = bj * TN + wc * (TN / WC) + j * 32 + l31;
       float v[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -587,6 +597,17 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmArgs g) {   // two wor
         }
       }
     }
+  }
+  };
+  if constexpr (SPLIT) {
+    if (bi & kHalfTile) {
+      bi &= ~kHalfTile;
+      tile_body(std::integral_constant<int, 64>{});
+    } else {
+      tile_body(std::integral_constant<int, TM>{});
+    }
+  } else {
+    tile_body(std::integral_constant<int, TM>{});
   }
 #ifdef EKF_GEMM_STAMP
   EKF_PHASE_STAMP(ph_t4);

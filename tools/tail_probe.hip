@@ -39,6 +39,49 @@ int main() {
     printf("K=%4d wgs=%3d tiles=%4d (%.2f rounds): %.1f us  %.3f us/tile/slot-round  %.1f TF\n", K, wgs, ntiles, (double)ntiles / wgs,
            best * 1e3, best * 1e3 / ((double)ntiles / wgs), 2.0 * ntiles * 128 * 128 * K / best / 1e9);
   }
+  // half tiles at the end of the list: the last `nsplit` tiles as two 64 x 128 halves each (kHalfTile)
+  {
+    float* S2; hipMalloc(&S2, (size_t)(n + 128) * ld * 4);
+    std::vector<float> r0((size_t)n * ld), r1((size_t)n * ld);
+    for (int nsplit : {0, 256, 384}) {
+      std::vector<int> tl(tm.begin(), tm.begin() + 2 * (nt - nsplit));
+      for (int t = nt - nsplit; t < nt; ++t)
+        for (int s2 = 0; s2 < 2; ++s2) { tl.push_back((2 * tm[2 * t] + s2) | kHalfTile); tl.push_back(tm[2 * t + 1]); }
+      const int ntl = (int)tl.size() / 2;
+      int* dtl; hipMalloc(&dtl, tl.size() * 4); hipMemcpy(dtl, tl.data(), tl.size() * 4, hipMemcpyHostToDevice);
+      // bit-identity against the unsplit list
+      if (nsplit == 0 || nsplit == 256) {
+        hipMemset(S2, 0, (size_t)(n + 128) * ld * 4);
+        GemmArgs a{V, ldy, V, ldy, S2, ld, 640, -1.0, 1.0, 2, 0, 0, 0, 0, dtl, ntl, counters + (cn++ % 60000), 0, 0, 1};
+        if (nsplit) k_gemm_mfma<ROLE_DOWNDATE, false, 128, 128, 8><<<512, 512>>>(a);
+        else k_gemm_mfma<ROLE_DOWNDATE, false><<<512, 256>>>(a);
+        hipMemcpy((nsplit ? r1 : r0).data(), S2, r0.size() * 4, hipMemcpyDeviceToHost);
+        if (nsplit) {
+          size_t bad = 0; for (size_t i = 0; i < r0.size(); ++i) bad += (r0[i] != r1[i]);
+          printf("split list vs plain list: %zu differing elements of %zu\n", bad, r0.size());
+        }
+      }
+      for (int K : {384, 640, 1024}) for (int wgs : {512, 448}) for (int nw : {4, 8}) {
+        float best = 1e9;
+        for (int pass = 0; pass < 3; ++pass) {
+          const int reps = 20;
+          hipDeviceSynchronize();
+          hipEventRecord(ea);
+          for (int r = 0; r < reps; ++r) {
+            GemmArgs a{V, ldy, V, ldy, S, ld, K, -1.0, 1.0, 2, 0, 0, 0, 0, dtl, ntl, counters + (cn++ % 60000), 0, 0, 1};
+            if (nw == 8) k_gemm_mfma<ROLE_DOWNDATE, false, 128, 128, 8><<<std::min(ntl, wgs), 512>>>(a);
+            else k_gemm_mfma<ROLE_DOWNDATE, false><<<std::min(ntl, wgs), 256>>>(a);
+          }
+          hipEventRecord(eb); hipEventSynchronize(eb);
+          float ms; hipEventElapsedTime(&ms, ea, eb); best = std::min(best, ms / reps);
+        }
+        printf("split %4d K=%4d wgs=%3d waves=%d: %.1f us  %.1f TF\n", nsplit, K, wgs, nw, best * 1e3, 2.0 * nt * 128 * 128 * K / best / 1e9);
+      }
+      hipFree(dtl);
+    }
+    hipFree(S2);
+  }
+  return 0;
   // ablation: what do the C tile read (beta = 1 -> 0) and the mirror stores (tri 2 -> 1) cost?
   for (int K : {384, 640, 1024}) for (int wgs : {512, 448}) {
     for (int var = 0; var < 4; ++var) {
