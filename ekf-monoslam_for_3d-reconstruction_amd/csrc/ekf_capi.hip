@@ -1415,7 +1415,7 @@ struct Filter : FilterBase {
         if (kIsF32 && opt_mfma && tri_count < num_cus)    // small map: 64 x 64 tiles, or most of the chip idles
           gemm<ROLE_DOWNDATE, false, 64, 64>(d_V + c0, ldy, d_V + c0, ldy, S(), ld, npad_live, npad_live, width, T(-1), T(1),
                                              2, 0, 0, 0, 0, ss, d_tilemap + tri64_off, tri64_count);
-        else if (opt_split_where & (ss == stream_b ? 2 : 1))
+        else if (kIsF32 && opt_mfma && (opt_split_where & (ss == stream_b ? 2 : 1)))   // half tiles: the 128 x 128 MFMA kernel only
           gemm<ROLE_DOWNDATE, false>(d_V + c0, ldy, d_V + c0, ldy, S(), ld, npad_live, npad_live, width, T(-1), T(1), 2, 0,
                                      0, 0, 0, ss, d_tilemap + trih_off, trih_count);
         else

@@ -389,7 +389,10 @@ __device__ unsigned long long ekf_phase_buf[8 * 1024];   // fetch, prologue, K l
 #endif
 
 template <int ROLE, bool BT, int TM = 128, int TN = 128, int NW = 4>
-__global__ void __launch_bounds__(64 * NW, NW / 2) k_gemm_mfma(GemmArgs g) {   // two workgroups per CU: NW / 2 waves per SIMD
+// Register budget: two 128 x 128 workgroups per CU (NW / 2 waves per SIMD each); the 64 x 64 chain tiles (ROLE_TRAILING)
+// are held to 80 registers so that one of them fits on a CU BESIDE two downdate workgroups (2 x 216 + 80 <= 512, LDS
+// 2 x 64 + 32 KiB): the trailing update of the chain then runs on every CU, not only on the ones the second stream leaves.
+__global__ void __launch_bounds__(64 * NW, (ROLE == ROLE_TRAILING && TM == 64 && TN == 64) ? 6 : NW / 2) k_gemm_mfma(GemmArgs g) {
   // TM x TN output tile (64 or 128 each), 4 waves as 2 x 2, each wave (TM/2) x (TN/2) = MI x NJ
   // accumulators of 32x32.  The small shapes exist for the latency-bound launches (chain tiles, tail of
   // the triangular solve): same flop, 2-4x the workgroups.
@@ -408,7 +411,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 2) k_gemm_mfma(GemmArgs g) {   /
   constexpr bool DUAL = (ROLE == ROLE_DOWNDATE) && !BT && TM == 128 && TN == 128;   // GemmArgs::B2 / C2
   const float alpha = float(g.alpha), beta = float(g.beta);
   __shared__ f32x4 lds[2 * NQ * (TM + TN)];   // two stages of {A image, B image}: one barrier per K step
-  __shared__ int s_tile;
+  // the queue's hand-over word lives in the first LDS slot (free between tiles: the body's first barrier separates its
+  // last reader from the first stage store): the workgroup then takes exactly 64 KiB (32 KiB for 64 x 64), and a
+  // 64 x 64 chain tile fits beside two 128 x 128 workgroups on a CU
+  int* const s_tile_p = reinterpret_cast<int*>(lds);
   constexpr int STAGE = NQ * (TM + TN);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -426,7 +432,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 2) k_gemm_mfma(GemmArgs g) {   /
   int ph_tiles = 0;
 #endif
   EKF_PHASE_STAMP(ph_t0);
-  while (gemm_next_tile(g, &s_tile, iter, bi, bj)) {
+  while (gemm_next_tile(g, s_tile_p, iter, bi, bj)) {
   EKF_PHASE_STAMP(ph_t1);
   auto tile_body = [&](auto tm_tag) {
   constexpr int TMb = decltype(tm_tag)::value, MI = TMb / 64, PA = TMb * 8 / NT;
@@ -565,28 +571,24 @@ __global__ void __launch_bounds__(64 * NW, NW / 2) k_gemm_mfma(GemmArgs g) {   /
   // epilogue: acc reg e of lane -> row (e&3) + 8*(e>>2) + 4*h, col l31 of the 32x32 tile
   const bool mirror = (TMb == TN || SPLIT) && (tri == 2) && (grow0 >= gcol0 + TN);
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    f32x16 cin[NJ];
-    if (beta != 0.f) {                         // the C loads of one 32-row band go out together, ahead of their use
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const float* Cp = C + (size_t)(bi * TMb + wr * (TMb / 2) + i * 32 + 4 * h) * ldc + bj * TN + wc * (TN / WC) + j * 32 + l31;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) cin[j][e] = beta * Cp[(size_t)((e & 3) + 8 * (e >> 2)) * ldc];
-      }
-    }
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int rbase = bi * TMb + wr * (TMb / 2) + i * 32;
       const int c = bj * TN + wc * (TN / WC) + j * 32 + l31;
       float v[16];
+      if (beta != 0.f) {                       // the 16 C loads of a 32 x 32 block go out together, ahead of their use
+        const float* Cp = C + (size_t)(rbase + 4 * h) * ldc + c;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int r = rbase + (e & 3) + 8 * (e >> 2) + 4 * h;
-        const float x = (beta != 0.f) ? __builtin_fmaf(alpha, acc[i][j][e], cin[j][e]) : alpha * acc[i][j][e];
-        v[e] = x;
-        C[(size_t)r * ldc + c] = x;
+        for (int e = 0; e < 16; ++e) v[e] = beta * Cp[(size_t)((e & 3) + 8 * (e >> 2)) * ldc];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = __builtin_fmaf(alpha, acc[i][j][e], v[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = alpha * acc[i][j][e];
       }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) C[(size_t)(rbase + (e & 3) + 8 * (e >> 2) + 4 * h) * ldc + c] = v[e];
       if (mirror) {
         // 4 consecutive regs are 4 consecutive rows -> one 16-byte store into the transposed tile
         float* Ct = C + (size_t)(c + g.col_off - g.row_off) * ldc + (g.row_off - g.col_off);
@@ -597,7 +599,6 @@ __global__ void __launch_bounds__(64 * NW, NW / 2) k_gemm_mfma(GemmArgs g) {   /
         }
       }
     }
-  }
   };
   if constexpr (SPLIT) {
     if (bi & kHalfTile) {
