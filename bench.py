@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--features", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-propagate-pass", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two short rocprofv3 --pmc child passes that measure `roofline.traffic` in this run")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-full", action="store_true",
                     help="also time ONE frame of the dense formulation on a single thread (minutes at N = 1000; for profiles/)")
@@ -222,7 +224,71 @@ def launch_ranks(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+def under_profiler():
+    """True when this process was started by rocprofv3 (its tool library is preloaded and has initialised the GPU: a
+    child must not be exec'd from here)."""
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower():
+        return True
+    return any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+
+
+def live_pmc_traffic(args):
+    """HBM bytes per launch of every kernel of THIS workload, measured now: two child runs of this script (5 steps)
+    under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `--pmc WRITE_SIZE --kernel-trace` (separate passes, counters
+    only; MI355X_MICROARCH.md, HBM section: KB per dispatch, the read counter doubled on gfx950).  Called before this
+    process touches the GPU.  Returns ({kernel: bytes per launch}, note) or (None, reason)."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    out = {}
+    work = tempfile.mkdtemp(prefix="ekf_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", EKF_BENCH_CHILD="1")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(work, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.abspath(__file__), "--features", str(args.features), "--steps", "5", "--warmup", "2",
+                   "--no-cpu-baseline", "--no-live-traffic", "--pipeline", str(args.pipeline)]
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                    start_new_session=True)
+            try:
+                rc = proc.wait(timeout=240)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)          # the process group of the child, nothing else
+                proc.wait()
+                return None, f"rocprofv3 --pmc {counter} child pass timed out"
+            files = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True))
+            if rc != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} child pass failed (rc {rc})"
+            acc = {}
+            for r in csv.DictReader(open(files[-1])):
+                if r.get("Counter_Name") != counter:
+                    continue
+                k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ekf::", "").replace("ekf::", "")
+                a = acc.setdefault(k, [0.0, 0])
+                a[0] += float(r["Counter_Value"])
+                a[1] += 1
+            for k, (tot, cnt) in acc.items():
+                out.setdefault(k, {})[counter] = tot / cnt
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    traffic = {k: {"hbm_bytes_per_launch": (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0} for k, v in out.items()}
+    return traffic, ("measured in this run: two child passes of this script (5 steps) under rocprofv3 --pmc FETCH_SIZE / "
+                     "--pmc WRITE_SIZE with --kernel-trace only; KB per dispatch, FETCH_SIZE x2 (gfx950)")
+
+
+LIVE_PMC = (None, None)
+
+
 def main():
+    global LIVE_PMC
     args = parse()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -231,6 +297,9 @@ def main():
         sys.exit(launch_ranks(args))
     if env_world is not None and int(env_world) != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={env_world} of the launcher")
+    if (env_world is None and args.gpus == 1 and not args.no_live_traffic and not os.environ.get("EKF_BENCH_CHILD")
+            and not under_profiler()):
+        LIVE_PMC = live_pmc_traffic(args)                # before anything here initialises the GPU
     import torch
     import torch.distributed as dist
     from __graft_entry__ import load_package
@@ -326,11 +395,16 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
                              "--pipeline 0 runs one launch" % pieces)
                             if pieces > 1 or args.pipeline != 0 else "one launch per step"}
 
-    # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside bench.py).  The
-    # counters belong to the kernel sources they were collected on: the file carries a fingerprint of csrc/, and
-    # `traffic` is reported only while it matches the sources of THIS run (else null, with the reason).
+    # HBM traffic per launch: measured by two rocprofv3 --pmc child passes of this run (live_pmc_traffic); when those are
+    # not available (child of a profiler, no rocprofv3, --no-live-traffic) from the committed PMC passes, which belong to
+    # the kernel sources they were collected on: the file carries a fingerprint of csrc/, and `traffic` is then reported
+    # only while it matches the sources of THIS run (else null, with the reason).
     pmc, pmc_note = {}, None
-    for tag in ("r2", "r1"):
+    if LIVE_PMC[0]:
+        pmc, pmc_note = LIVE_PMC
+    elif LIVE_PMC[1]:
+        pmc_note = LIVE_PMC[1]
+    for tag in (() if pmc else ("r2", "r1")):
         pmc_path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
         if n_feat == 1000 and os.path.exists(pmc_path):
             doc = json.load(open(pmc_path))
@@ -338,6 +412,8 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
                 pmc = doc["kernels"]
                 pmc_note = (f"profiles/{tag}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                             f"FETCH_SIZE x2), collected on these kernel sources (csrc sha {doc['csrc_sha16']})")
+                if LIVE_PMC[1]:
+                    pmc_note = f"live pass unavailable ({LIVE_PMC[1]}); " + pmc_note
             else:
                 pmc_note = (f"profiles/{tag}_pmc_traffic.json predates the kernel sources of this run "
                             f"(csrc sha {doc.get('csrc_sha16')} != {csrc_sha()}): traffic not reported")
