@@ -550,8 +550,11 @@ __global__ void __launch_bounds__(64 * NW, (ROLE == ROLE_TRAILING && TM == 64 &&
   EKF_PHASE_STAMP(ph_t2);
   read_frag(0, 0, 0);
   int stage = 0;
-  for (int k0 = 0; k0 < K; k0 += BK, stage ^= 1) {
-    const bool more = k0 + BK < K;
+  // one K step; `more` (another step follows: stage the tile in registers) and `more2` (one more after that: fetch it)
+  // are compile-time, so the steady-state step is ONE basic block and the scheduler may place the ds_writes and the
+  // global loads between the MFMAs instead of behind a branch after them
+  auto kstep = [&](auto more_t, auto more2_t, int k0) {
+    constexpr bool more = decltype(more_t)::value, more2 = decltype(more2_t)::value;
 #pragma unroll
     for (int s = 0; s < NG; ++s) {
       if (s + 1 < NG) {
@@ -563,9 +566,18 @@ __global__ void __launch_bounds__(64 * NW, (ROLE == ROLE_TRAILING && TM == 64 &&
       mfma_group(s & 1);
       if (s == 0 && more) {
         store_tile(stage ^ 1);
-        if (k0 + 2 * BK < K) load_tile(k0 + 2 * BK);
+        if (more2) load_tile(k0 + 2 * BK);
       }
     }
+    stage ^= 1;
+  };
+  {
+    using yes = std::true_type;
+    using no = std::false_type;
+    int k0 = 0;
+    for (; k0 + 2 * BK < K; k0 += BK) kstep(yes{}, yes{}, k0);
+    if (k0 + BK < K) { kstep(yes{}, no{}, k0); k0 += BK; }
+    kstep(no{}, no{}, k0);
   }
   EKF_PHASE_STAMP(ph_t3);
   // epilogue: acc reg e of lane -> row (e&3) + 8*(e>>2) + 4*h, col l31 of the 32x32 tile
