@@ -567,6 +567,9 @@ __global__ void __launch_bounds__(64 * NW, (ROLE == ROLE_TRAILING && TM == 64 &&
       if (s == 0 && more) {
         store_tile(stage ^ 1);
         if (more2) load_tile(k0 + 2 * BK);
+        // (left alone, the scheduler sinks these loads to the end of the step, ~600 cycles before the stores that
+        // consume them; pinning them here with sched_barrier(0), a whole step ahead, measured SLOWER: a 2-round
+        // K = 1024 launch 337 against 292 us, the step 1.332 against 1.320 ms)
       }
     }
     stage ^= 1;
