@@ -384,11 +384,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // with this macro.
 __device__ unsigned long long ekf_stamp_buf[4 * 1024];
 __device__ unsigned long long ekf_phase_buf[8 * 1024];   // fetch, prologue, K loop, epilogue cycles; tiles
+__device__ unsigned long long ekf_loop_buf[8 * 1024];    // inside the K loop (EKF_GEMM_LOOPSTAMP): group 0 + stores, groups 1-2, barrier, group 3; steps
 #define EKF_PHASE_STAMP(var) \
   do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); \
        __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define EKF_PHASE_STAMP(var) do { } while (0)
+#endif
+#if defined(EKF_GEMM_STAMP) && defined(EKF_GEMM_LOOPSTAMP)
+#define EKF_LOOP_STAMP(var) EKF_PHASE_STAMP(var)
+#else
+#define EKF_LOOP_STAMP(var) do { } while (0)
 #endif
 
 template <int ROLE, bool BT, int TM = 128, int TN = 128, int NW = 4>
@@ -432,6 +438,7 @@ __global__ void __launch_bounds__(64 * NW, (ROLE == ROLE_TRAILING && TM == 64 &&
     ekf_stamp_buf[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
   }
   unsigned long long ph_t0 = 0, ph_t1 = 0, ph_t2 = 0, ph_t3 = 0, ph_t4 = 0, ph_sum[4] = {0, 0, 0, 0};
+  unsigned long long lp_t[5] = {0, 0, 0, 0, 0}, lp_sum[4] = {0, 0, 0, 0}, lp_steps = 0;
   int ph_tiles = 0;
 #endif
   EKF_PHASE_STAMP(ph_t0);
@@ -558,15 +565,19 @@ __global__ void __launch_bounds__(64 * NW, (ROLE == ROLE_TRAILING && TM == 64 &&
   // global loads between the MFMAs instead of behind a branch after them
   auto kstep = [&](auto more_t, auto more2_t, int k0) {
     constexpr bool more = decltype(more_t)::value, more2 = decltype(more2_t)::value;
+    EKF_LOOP_STAMP(lp_t[0]);
 #pragma unroll
     for (int s = 0; s < NG; ++s) {
       if (s + 1 < NG) {
         read_frag(stage, s + 1, (s + 1) & 1);
       } else {
+        EKF_LOOP_STAMP(lp_t[2]);
         __syncthreads();                       // stage^1 is complete, everybody has read this stage
+        EKF_LOOP_STAMP(lp_t[3]);
         if (more) read_frag(stage ^ 1, 0, 0);
       }
       mfma_group(s & 1);
+      if (s == 0) EKF_LOOP_STAMP(lp_t[1]);
       if (s == 0 && more) {
         store_tile(stage ^ 1);
         if (more2) load_tile(k0 + 2 * BK);
@@ -591,6 +602,13 @@ __global__ void __launch_bounds__(64 * NW, (ROLE == ROLE_TRAILING && TM == 64 &&
         // K = 1024 launch 337 against 292 us, the step 1.332 against 1.320 ms)
       }
     }
+#if defined(EKF_GEMM_STAMP) && defined(EKF_GEMM_LOOPSTAMP)
+    EKF_LOOP_STAMP(lp_t[4]);
+    if (more && more2) {
+      lp_sum[0] += lp_t[1] - lp_t[0]; lp_sum[1] += lp_t[2] - lp_t[1]; lp_sum[2] += lp_t[3] - lp_t[2]; lp_sum[3] += lp_t[4] - lp_t[3];
+      ++lp_steps;
+    }
+#endif
     stage ^= 1;
   };
   {
@@ -656,6 +674,8 @@ __global__ void __launch_bounds__(64 * NW, (ROLE == ROLE_TRAILING && TM == 64 &&
     ekf_stamp_buf[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
     ekf_stamp_buf[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
     for (int q = 0; q < 4; ++q) ekf_phase_buf[8 * blockIdx.x + q] = ph_sum[q];
+    for (int q = 0; q < 4; ++q) ekf_loop_buf[8 * blockIdx.x + q] = lp_sum[q];
+    ekf_loop_buf[8 * blockIdx.x + 4] = lp_steps;
     ekf_phase_buf[8 * blockIdx.x + 4] = ph_tiles;
   }
 #endif
