@@ -75,7 +75,10 @@ enum ekf_option {
    * 2 around every kernel, 3 as 1 but only in every 8th update since the last ekf_profile_reset (each pair of
    * events costs ~6 microseconds of queue time: 5 % of a step at N = 200). */
   EKF_OPT_PROFILE = 2,
-  /* Chunked factorisation: 0 = one chunk, one stream (plain blocked Cholesky + one solve + one downdate);
+  /* Chunked factorisation: 0 = one chunk, one stream (plain blocked Cholesky + one solve + one downdate; for A/B runs:
+   * the solve then goes through the explicit inverse of the WHOLE factor, and Sigma after an update is an order of
+   * magnitude further from the fp64 result than on the default path at 2M >= 2000 -- 1.2e-4 against 1.2e-5 of
+   * max|Sigma|, tools/acc_check_sizes.py);
    * 1 = the default three column chunks, the solve / W-update / downdate of every chunk but the last on a
    * second, CU-masked stream beside the serial chain; k >= 2 = k equal chunks;
    * -1 (default): as 1 when the chain has at least 8 block steps (m >= 1024), else as 0. */
