@@ -8,7 +8,7 @@ from __graft_entry__ import load_package
 pkg = load_package()
 from ekf_monoslam_amd import synthetic
 cfg = pkg.kinect_config()
-for N in (1200, 2000):
+for N in ([int(a) for a in sys.argv[1:]] or [1200, 2000]):
     px0, z = synthetic.measurement_stream(cfg, N, 4, sigma_px=0.5)
     idx = np.arange(N, dtype=np.int32)
     res = {}
