@@ -372,9 +372,6 @@ __global__ void __launch_bounds__(256) k_gemm_valu(GemmArgs g) {
 // MFMA e multiplies k = 8s + 4h + e, the same permutation on A and B, so the sum is exact.
 // NN mode stages B by 4x4 register transposes of row-major [k][col] quads.
 // ---------------------------------------------------------------------------------------
-#ifndef EKF_SGB_ALL
-#define EKF_SGB_ALL 0
-#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -582,7 +579,7 @@ __global__ void __launch_bounds__(64 * NW, (ROLE == ROLE_TRAILING && TM == 64 &&
         store_tile(stage ^ 1);
         if (more2) load_tile(k0 + 2 * BK);
 #ifndef EKF_NO_SGB
-        if constexpr (more && more2 && NW == 4 && (EKF_SGB_ALL || (TMb == 128 && TN == 128 && !BT))) {
+        if constexpr (more && more2 && NW == 4 && !BT && TN == 128) {
           // steady state: one ds_write after every few MFMAs of this group instead of all of them in a row behind it
           // (the stores wait for their global loads one by one; in a row they leave the matrix pipe with one
           // instruction in flight).  128 x 128 NT tile: alone on a CU a K = 1024 tile 85.8 -> 79.1 us, the 1128-tile
@@ -594,7 +591,8 @@ __global__ void __launch_bounds__(64 * NW, (ROLE == ROLE_TRAILING && TM == 64 &&
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);    // one ds_write
           }
           // (also tried: one write per MFMA; the global loads spread the same way after the writes, one per MFMA or
-          // per two: each 2 % slower on the 1128-tile launch; the same hint on the 64-row and NN tiles: step +0.6 %)
+          // per two: each 2 % slower on the 1128-tile launch.  Shapes: NT tiles with 128 columns -- 128 x 128 and the
+          // 64 x 128 of the W update and of the half tiles -- gain; the 64 x 64 chain tiles and the NN solve tiles lose)
         }
 #endif
         // (left alone, the scheduler sinks these loads to the end of the step, ~600 cycles before the stores that
