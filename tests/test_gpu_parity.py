@@ -767,6 +767,42 @@ def test_dataflow_launch_is_bit_identical(monkeypatch):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("knobs", [
+    {"EKF_SPLIT_TAIL": "0"},                                     # no half tiles at the end of the downdate's list
+    {"EKF_SPLIT_TAIL": "200", "EKF_SPLIT_WHERE": "3"},           # half tiles on the main AND the second stream
+    {"EKF_GEMM_WAVES": "8"},                                     # 128 x 128 tiles on eight-wave workgroups
+    {"EKF_FUSE_WU": "0"}, {"EKF_FUSE_WU": "2"},                  # W update and downdate never / always in one launch
+    {"EKF_XCD_QUEUES": "1"},                                     # one queue head per XCD
+])
+def test_launch_structure_knobs_are_bit_identical(monkeypatch, knobs):
+    """The tuning knobs of DESIGN.md section 3 change WHICH workgroup computes a tile and in what tile shape, never the
+    arithmetic of an element: mu and Sigma equal the default configuration to the last bit."""
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from ekf_monoslam_amd import synthetic
+    cfg = pkg.kinect_config()
+    n_feat = 640
+    px0, z = synthetic.measurement_stream(cfg, n_feat, 3, sigma_px=0.5)
+    idx = np.arange(n_feat, dtype=np.int32)
+    outs = []
+    for env in ({}, knobs):
+        for k in ("EKF_SPLIT_TAIL", "EKF_SPLIT_WHERE", "EKF_GEMM_WAVES", "EKF_FUSE_WU", "EKF_XCD_QUEUES"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)                             # read when the filter is created
+        f = pkg.VSlamFilter(cfg, capacity_features=n_feat)
+        f.setDt(1.0 / 30.0)
+        for (u, v) in px0:
+            assert f.addFeature((u, v)) == 1
+        for k in range(3):
+            f.predict()
+            f.update(z[k].reshape(-1), idx)
+        f.synchronize()
+        outs.append((f.getFullState(), f.getFullSigma()))
+        f.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_profile_reports_time_and_work_of_the_downdate():
     """EKF_OPT_PROFILE = 1 times the downdate launches with HIP events; ekf_profile_work reports their algorithmic
     flop: n^2 x the measured columns (symmetric half) plus, for the launch that carries its chunk's W update,
