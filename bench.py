@@ -259,7 +259,7 @@ def live_pmc_traffic(args):
             proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                                     start_new_session=True)
             try:
-                rc = proc.wait(timeout=240)
+                rc = proc.wait(timeout=180)
             except subprocess.TimeoutExpired:
                 os.killpg(proc.pid, signal.SIGKILL)          # the process group of the child, nothing else
                 proc.wait()
