@@ -91,7 +91,6 @@ _PROTOS = {
     "ekf_set_sigma_block": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ekf_covariance_parameter": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "ekf_feature_xyz": (C.c_int, [_P, C.c_int, _P, _P]),
-    "ekf_debug_flow_trace": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
     "ekf_check_invariants": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ekf_profile_kernels": (C.c_int, []),
     "ekf_profile_kernel_name": (C.c_char_p, [C.c_int]),

@@ -17,7 +17,6 @@
 #include "ekf_split.hpp"
 #include "ekf_kernels.hpp"
 #include "ekf_shard.hpp"
-#include "ekf_flow.hpp"
 
 namespace ekf {
 
@@ -46,7 +45,6 @@ enum KernelId : int {
   KID_GATHER_S,
   KID_GATHER_V,
   KID_GATHER_SIGMA,
-  KID_FLOW,
   KID_COUNT
 };
 
@@ -55,8 +53,7 @@ static const char* kKernelNames[KID_COUNT] = {
     "innovation",      "sigma_ht",         "innovation_cov",      "chol_diag",
     "chol_panel",      "chol_trailing",    "state_update",        "downdate_syrk",
     "solve_trmm",      "normalize_quat",  "add_feature",      "compact_transform",   "misc",
-    "w_update", "allgather_h", "allgather_s", "allgather_v", "allgather_sigma",
-    "flow_gemm"};
+    "w_update", "allgather_h", "allgather_s", "allgather_v", "allgather_sigma"};
 
 static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
@@ -88,7 +85,6 @@ struct FilterBase {
   virtual int set_sigma(const void*, int, int, int, int) = 0;
   virtual int covariance_parameter(double*) = 0;
   virtual int check_invariants(double*, double*, double*) = 0;
-  virtual int flow_trace(unsigned long long*, int, int*) = 0;
   virtual int feature_xyz(int, void*, void*) = 0;
   virtual int profile_read(int, double*, long long*) = 0;
   virtual int profile_reset() = 0;
@@ -181,11 +177,9 @@ struct Filter : FilterBase {
   int opt_chain_mask = 0;                               // 1: chain of chunks >= 1 on the reserved CUs only (measured slower: the trailing updates want more CUs)
   int solve64_off = 0, solve6464_off = 0, tri64_off = 0, tri64_count = 0;
   int trih_off = 0, trih_count = 0;                      // the 128 x 128 list with its last opt_split_tail tiles as 64 x 128 halves
-  int opt_gemm_waves = 4, opt_gemm_waves_where = 7;      // EKF_GEMM_WAVES=8: 128 x 128 tile GEMMs with eight waves (where: 1 downdate, 2 W update, 4 solve)
-  // EKF_SPLIT_TAIL (-1: 1.5 tiles per CU, at most a third of the list) / EKF_SPLIT_WHERE (1: downdate on the main stream,
-  // 2: on the side stream).  Measured at N = 1000: 384 halves on the last downdate 1.348 -> 1.329 ms; on the CU-masked side
-  // stream no gain; eight-wave workgroups (EKF_GEMM_WAVES=8) 3-5 % faster per launch alone, nothing in the step.
-  int opt_split_tail = -1, opt_split_where = 1;
+  // EKF_SPLIT_TAIL (-1: 1.5 tiles per CU, at most a third of the list): tiles at the end of the LAST downdate's queued list
+  // that go out as 64 x 128 halves.  Measured at N = 1000: 384 halves 1.348 -> 1.329 ms (on the CU-masked side stream: no gain).
+  int opt_split_tail = -1;
   double opt_feature_noise = 0.0;                       // EKF_OPT_FEATURE_NOISE: variance added to every feature state per predict
   int opt_split_bf16 = 0;                               // EKF_OPT_SPLIT_BF16: downdate on the bf16 matrix pipe, 3 x bf16 per operand
   __bf16* d_Vs[3] = {nullptr, nullptr, nullptr};
@@ -202,16 +196,7 @@ struct Filter : FilterBase {
   unsigned char* d_found = nullptr;
   float* d_score = nullptr;
   int* d_keep = nullptr;
-  int opt_flow = 0;                                     // EKF_FLOW=1: ONE persistent dataflow launch for every solve / W-update / downdate tile (csrc/ekf_flow.hpp); measured slower than the launch-per-phase path (1.49 vs 1.34 ms at N = 1000: the tiles themselves run at the same ~68 % of the MFMA peak and the chain beside a permanently full chip slows down), kept for A/B runs
-  FlowTask* d_flow_tasks = nullptr;
-  unsigned long long* d_flow_trace = nullptr;
-  int* d_flow_counters = nullptr;
-  size_t flow_tasks_cap = 0, flow_counters_cap = 0;
-  int flow_ntasks = 0, flow_ncounters = 0;
-  double flow_flop = 0.0;
-  std::vector<int> flow_key;                            // (npad_live, m, m_pad, chunk ends) the cached list was built for
   int opt_panel_direct = 1;                             // EKF_PANEL_DIRECT=0: panel through the general tile GEMM
-  int opt_xcd_queues = 0;                               // EKF_XCD_QUEUES=1: one queue head per XCD for the downdate launches (HBM traffic 561 -> 467 MB per launch, step time +0.6 %: off)
   int opt_fuse_wu = 1;                                  // EKF_FUSE_WU: 0 never, 1 every overlapped chunk but the one before the last, 2 every overlapped chunk
   int env_chunks[8] = {}, env_nchunks = 0;               // EKF_CHUNKS="5,10,14,16": tuning knob (block steps)
   int opt_pipeline = -1;                                 // -1 auto: on when the chain has >= 8 block steps
@@ -245,7 +230,7 @@ struct Filter : FilterBase {
                     d_flags, d_cflag, d_Jy, d_Yxyz, d_map_src, d_map_conv, d_Y, d_W, d_V, d_Dinv, d_z, d_midx,
                     d_status, d_tmp, d_K, d_tilemap, d_counters, d_ibuf, d_rmask, d_pts,
                     d_frame, d_patch[0], d_patch[1], d_mpatch[0], d_mpatch[1], d_hb, d_zm, d_found, d_score, d_keep,
-                    d_Vs[0], d_Vs[1], d_Vs[2], d_stage_send, d_stage_recv, d_flow_tasks, d_flow_counters, d_flow_trace};
+                    d_Vs[0], d_Vs[1], d_Vs[2], d_stage_send, d_stage_recv};
     for (void* p : ptrs) if (p) hipFree(p);
     if (own_stream && stream) hipStreamDestroy(stream);
     if (stream_b) hipStreamDestroy(stream_b);
@@ -263,7 +248,7 @@ struct Filter : FilterBase {
   // ---- profiling helpers ---------------------------------------------------------------
   bool prof_on(int kid) const {
     if (opt_profile == 2) return true;
-    const bool dominant = (kid == KID_DOWNDATE || kid == KID_PROPAGATE_STREAMING || kid == KID_FLOW);
+    const bool dominant = (kid == KID_DOWNDATE || kid == KID_PROPAGATE_STREAMING);
     if (opt_profile == 1) return dominant;
     if (opt_profile == 3) return dominant && (frame_seq % kProfileSamplePeriod == 0);   // every 8th frame: an event pair costs ~6 us of queue time
     return false;
@@ -399,13 +384,8 @@ struct Filter : FilterBase {
       }
       if (const char* e = getenv("EKF_CHAIN_MASK")) opt_chain_mask = atoi(e);
       if (const char* e = getenv("EKF_FUSE_WU")) opt_fuse_wu = atoi(e);
-      if (const char* e = getenv("EKF_XCD_QUEUES")) opt_xcd_queues = atoi(e);
       if (const char* e = getenv("EKF_PANEL_DIRECT")) opt_panel_direct = atoi(e);
-      if (const char* e = getenv("EKF_FLOW")) opt_flow = atoi(e);
-      if (const char* e = getenv("EKF_GEMM_WAVES")) opt_gemm_waves = atoi(e);
-      if (const char* e = getenv("EKF_GEMM_WAVES_WHERE")) opt_gemm_waves_where = atoi(e);
       if (const char* e = getenv("EKF_SPLIT_TAIL")) opt_split_tail = atoi(e);
-      if (const char* e = getenv("EKF_SPLIT_WHERE")) opt_split_where = atoi(e);
       if (const char* e = getenv("EKF_CHUNKS")) {           // tuning knob: chunk ends in block steps
         for (const char* q = e; *q && env_nchunks < 8;) {
           env_chunks[env_nchunks++] = atoi(q);
@@ -456,9 +436,8 @@ struct Filter : FilterBase {
     int st[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(st, d_status, sizeof(st), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
-    if (st[0] || st[1] || st[3]) {
+    if (st[0] || st[1]) {
       HIPCHK(hipMemsetAsync(d_status, 0, 4 * sizeof(int), stream));
-      if (st[3]) FAIL(EKF_ERR_DEVICE, "dataflow launch: a tile waited for its inputs for seconds and gave up (EKF_FLOW)");
       if (st[1])
         FAIL(EKF_ERR_ARG, "ekf_update_device: a device-resident index is outside [0, N) or the list is not strictly "
                           "ascending (indices were clamped; the state is not meaningful)");
@@ -862,7 +841,6 @@ struct Filter : FilterBase {
       g.ntiles = ntiles;
       g.counter = d_counters + counter_next;
       counter_next += 8;
-      g.xcd_queues = (ROLE == ROLE_DOWNDATE) ? opt_xcd_queues : 0;
       // persistent grid: two workgroups per CU the stream may use
       const bool side = (st == stream_b);
       const int wgs = 2 * (side ? (num_cus - reserved_cus) : num_cus);
@@ -870,13 +848,6 @@ struct Filter : FilterBase {
     }
     if constexpr (kIsF32) {
       if (opt_mfma) {
-        if constexpr (TM == 128 && TN == 128 && (ROLE == ROLE_DOWNDATE || ROLE == ROLE_WUPDATE || ROLE == ROLE_SOLVE)) {
-          if (opt_gemm_waves == 8 && (ROLE != ROLE_SOLVE || (opt_gemm_waves_where & 4)) &&
-              (ROLE != ROLE_WUPDATE || (opt_gemm_waves_where & 2))) {
-            k_gemm_mfma<ROLE, BT, TM, TN, 8><<<grid, 512, 0, st>>>(g);
-            return;
-          }
-        }
         k_gemm_mfma<ROLE, BT, TM, TN><<<grid, 256, 0, st>>>(g);
         return;
       }
@@ -1051,101 +1022,6 @@ struct Filter : FilterBase {
     return EKF_OK;
   }
 
-  // ---- persistent dataflow launch (csrc/ekf_flow.hpp) ---------------------------------------------------------
-  // Task list + counter layout for (npad_live, m_pad, chunk plan); cached on the device until one of them changes.
-  int ensure_flow(int npad_live, int m, int m_pad, int nchunks, const int* cend) {
-    const int nb = 128;
-    std::vector<int> key = {npad_live, m, m_pad, nchunks};
-    for (int g = 0; g < nchunks; ++g) key.push_back(cend[g]);
-    if (key == flow_key) return EKF_OK;
-    const int ntr = (npad_live + nb) / nb;               // row tiles of [W; nu^T] / V
-    const int nts = npad_live / nb;                      // row / column tiles of Sigma
-    const int ntc = m_pad / nb;                          // column tiles of W / V
-    // counters: [0] queue head, [1] chain_done, vdone[g][i], wdone[t][i], wver[i][c], sver[I (I + 1) / 2 + J]
-    const int base_v = 2, base_w = base_v + 8 * ntr, base_wv = base_w + 8 * ntr, base_s = base_wv + ntr * ntc;
-    const int ncount = base_s + nts * (nts + 1) / 2;
-    std::vector<FlowTask> tasks;
-    double flop = 0.0;
-    auto chunk_of_tile = [&](int c) { for (int g = 0; g < nchunks; ++g) if (c < cend[g]) return g; return nchunks - 1; };
-    for (int g = 0; g < nchunks; ++g) {
-      const int s0 = g ? cend[g - 1] : 0, s1 = cend[g];  // column tiles of the chunk
-      const int c0 = s0 * nb, wt = s1 - s0, width = wt * nb;
-      const int real = std::max(0, std::min(s1 * nb, m) - std::min(c0, m));
-      // solves: heaviest (largest j) first
-      for (int j = wt - 1; j >= 0; --j)
-        for (int i = 0; i < ntr; ++i) {
-          FlowTask t{};
-          t.type = FLOW_SOLVE; t.K = (j + 1) * nb;
-          t.a_off = (long long)i * nb * ldy + c0;
-          t.b_off = (long long)c0 + (long long)j * nb;
-          t.c_off = (long long)i * nb * ldy + c0 + (long long)j * nb;
-          t.bi = i; t.bj = j;
-          t.dep[0] = 1; t.need[0] = g + 1;
-          t.dep[1] = g ? base_w + g * ntr + i : -1; t.need[1] = wt * g;
-          t.dep[2] = -1; t.need[2] = 0;
-          t.sig[0] = base_v + g * ntr + i; t.sig[1] = -1;
-          tasks.push_back(t);
-        }
-      flop += double(npad_live + nb) * width * (width + nb);          // sum over j of 2 rows nb (j + 1) nb
-      // right-looking update of the later columns of W, next chunk's columns first
-      for (int c = s1; c < ntc; ++c)
-        for (int i = 0; i < ntr; ++i) {
-          FlowTask t{};
-          t.type = FLOW_WUPDATE; t.K = width;
-          t.a_off = (long long)i * nb * ldy + c0;
-          t.b_off = (long long)c * nb * ldy + c0;
-          t.c_off = (long long)i * nb * ldy + (long long)c * nb;
-          t.bi = i; t.bj = c;
-          t.dep[0] = base_v + g * ntr + i; t.need[0] = wt;
-          t.dep[1] = g ? base_wv + i * ntc + c : -1; t.need[1] = g;
-          t.dep[2] = -1; t.need[2] = 0;
-          t.sig[0] = base_w + chunk_of_tile(c) * ntr + i; t.sig[1] = base_wv + i * ntc + c;
-          tasks.push_back(t);
-        }
-      flop += 2.0 * double(npad_live + nb) * double(m_pad - s1 * nb) * width;
-      // downdate of the lower tiles, 8 x 8 super-tiles (tiles in flight share their panels in L2)
-      const int SB = 8, ns = (nts + SB - 1) / SB;
-      for (int si = 0; si < ns; ++si)
-        for (int sj = 0; sj <= si; ++sj)
-          for (int I = si * SB; I < std::min(nts, (si + 1) * SB); ++I)
-            for (int J = sj * SB; J < std::min(nts, (sj + 1) * SB); ++J) {
-              if (J > I) continue;
-              FlowTask t{};
-              t.type = FLOW_DOWNDATE; t.K = width;
-              t.a_off = (long long)I * nb * ldy + c0;
-              t.b_off = (long long)J * nb * ldy + c0;
-              t.c_off = (long long)I * nb * ld + (long long)J * nb;
-              t.bi = I; t.bj = J;
-              t.dep[0] = base_v + g * ntr + I; t.need[0] = wt;
-              t.dep[1] = (J != I) ? base_v + g * ntr + J : -1; t.need[1] = wt;
-              t.dep[2] = g ? base_s + I * (I + 1) / 2 + J : -1; t.need[2] = g;
-              t.sig[0] = base_s + I * (I + 1) / 2 + J; t.sig[1] = -1;
-              tasks.push_back(t);
-            }
-      flop += double(n) * n * real;                      // symmetric half, 2 flop per multiply-add: the algorithmic count of SURVEY 8d
-    }
-    HIPCHK(hipStreamSynchronize(stream));
-    if (stream_b) HIPCHK(hipStreamSynchronize(stream_b));
-    if (tasks.size() > flow_tasks_cap) {
-      if (d_flow_tasks) HIPCHK(hipFree(d_flow_tasks));
-      d_flow_tasks = nullptr;
-      HIPCHK(hipMalloc(&d_flow_tasks, tasks.size() * sizeof(FlowTask)));
-      flow_tasks_cap = tasks.size();
-    }
-    if ((size_t)ncount > flow_counters_cap) {
-      if (d_flow_counters) HIPCHK(hipFree(d_flow_counters));
-      d_flow_counters = nullptr;
-      HIPCHK(hipMalloc(&d_flow_counters, (size_t)ncount * sizeof(int)));
-      flow_counters_cap = ncount;
-    }
-    HIPCHK(hipMemcpy(d_flow_tasks, tasks.data(), tasks.size() * sizeof(FlowTask), hipMemcpyHostToDevice));
-    flow_ntasks = (int)tasks.size();
-    flow_ncounters = ncount;
-    flow_flop = flop;
-    flow_key = key;
-    return EKF_OK;
-  }
-
   // Block steps [step0, step1) of the serial chain of chunk [c0, c1) on stream sc_: diagonal factor, panel (rows
   // below the block + the chunk's identity-strip rows), trailing update (strip tiles stop at c1).
   void chain_steps(int step0, int step1, int c0, int c1, int m, int m_pad, hipStream_t sc_) {
@@ -1251,51 +1127,10 @@ struct Filter : FilterBase {
     rc = ensure_tilemap(npad_live / tile, ntr, ntc);
     if (rc) return rc;
 
-    bool use_flow = false;
-    if constexpr (kIsF32)
-      use_flow = opt_flow && opt_mfma && nchunks > 1 && stream_b && tile == 128 && tri_count >= num_cus && !opt_split_bf16;
-    if (use_flow) {
-      if constexpr (kIsF32) {
-        rc = ensure_flow(npad_live, m, m_pad, nchunks, cend);
-        if (rc) return rc;
-        HIPCHK(hipMemsetAsync(d_flow_counters, 0, (size_t)flow_ncounters * sizeof(int), stream));
-        FlowArgs fa{d_W, d_V, d_Y, Zs, S(), d_W, ldy, ld, d_flow_tasks, flow_ntasks, d_flow_counters, d_flow_counters, d_status, 1,
-                    nullptr};
-        if (getenv("EKF_FLOW_TRACE")) {                  // diagnostic: per-task time stamps, dumped by tools/flow_trace.py
-          if (!d_flow_trace) HIPCHK(hipMalloc(&d_flow_trace, flow_tasks_cap * 4 * sizeof(unsigned long long)));
-          fa.trace = d_flow_trace;
-        }
-        int step = 0;
-        for (int gi = 0; gi < nchunks; ++gi) {
-          const int c0 = step * nb, c1 = cend[gi] * nb;
-          chain_steps(step, cend[gi], c0, c1, m, m_pad, stream);
-          step = cend[gi];
-          k_flow_chain_done<<<1, 64, 0, stream>>>(d_flow_counters + 1, gi + 1);
-          if (gi == 0) {
-            // the persistent grid starts when the first chunk of the chain is done (that chunk has the chip to itself;
-            // a grid started earlier would only poll); its later tiles wait for the chain chunk by chunk
-            HIPCHK(hipEventRecord(ev_chain[0], stream));
-            HIPCHK(hipStreamWaitEvent(stream_b, ev_chain[0], 0));
-            Scope sc(this, KID_FLOW, stream_b);
-            if (sc.on) prof_work[KID_FLOW] += flow_flop;
-            const int wgs = 2 * (num_cus - reserved_cus);
-            k_gemm_flow<<<std::min(flow_ntasks, wgs), 256, 0, stream_b>>>(fa);
-          }
-        }
-        // the chain's CUs are free now: a second instance of the same grid joins the queue on them
-        if (reserved_cus > 0) k_gemm_flow<<<2 * reserved_cus, 256, 0, stream>>>(fa);
-        HIPCHK(hipEventRecord(ev_b, stream_b));
-        HIPCHK(hipStreamWaitEvent(stream, ev_b, 0));
-        {
-          Scope sc(this, KID_STATE_UPDATE);              // every column of V and y exist once both grids have drained
-          k_state_update<T><<<(n + 7) / 8, 512, 0, stream>>>(mu(), d_V, ldy, n, d_V + (size_t)npad_live * ldy, m_pad, d_scr + SCR_QN);
-        }
-      }
-    }
     int step = 0;
     bool b_inflight = false;
     bool c_inflight = false;
-    for (int gi = 0; gi < (use_flow ? 0 : nchunks); ++gi) {
+    for (int gi = 0; gi < nchunks; ++gi) {
       const int c0 = step * nb, c1 = cend[gi] * nb;
       // chunk 0 has the chip to itself; later chunks run beside the tile GEMMs of stream_b, on the reserved CUs
       hipStream_t sc_ = (opt_chain_mask && nchunks > 1 && gi > 0) ? stream_c : stream;
@@ -1400,13 +1235,11 @@ struct Filter : FilterBase {
           }
           const int nr2 = (npad_live + nb) / 128, n2 = nr2 * ((m_pad - c1) / 128);
           GemmArgs g{d_V + c0, ldy, d_V + c0, ldy, S(), ld, width, -1.0, 1.0, 2, 0, 0, 0, 0,
-                     (opt_split_where & 2) ? d_tilemap + trih_off : d_tilemap, n2 + ((opt_split_where & 2) ? trih_count : tri_count),
-                     d_counters + counter_next, 0, 0, 1,
-                     Y + (size_t)c1 * ldy + c0, ldy, d_W + c1, ldy, n2, nr2, opt_xcd_queues};
+                     d_tilemap, n2 + tri_count, d_counters + counter_next, 0, 0, 1,
+                     Y + (size_t)c1 * ldy + c0, ldy, d_W + c1, ldy, n2, nr2};
           counter_next += 8;
           const int wgs = 2 * (num_cus - reserved_cus);
-          if (opt_gemm_waves == 8) k_gemm_mfma<ROLE_DOWNDATE, false, 128, 128, 8><<<std::min(g.ntiles, wgs), 512, 0, ss>>>(g);
-          else k_gemm_mfma<ROLE_DOWNDATE, false><<<std::min(g.ntiles, wgs), 256, 0, ss>>>(g);
+          k_gemm_mfma<ROLE_DOWNDATE, false><<<std::min(g.ntiles, wgs), 256, 0, ss>>>(g);
           HIPCHK(hipEventRecord(ev_wu, stream_b));
         }
       } else if (!split_done) {
@@ -1415,7 +1248,7 @@ struct Filter : FilterBase {
         if (kIsF32 && opt_mfma && tri_count < num_cus)    // small map: 64 x 64 tiles, or most of the chip idles
           gemm<ROLE_DOWNDATE, false, 64, 64>(d_V + c0, ldy, d_V + c0, ldy, S(), ld, npad_live, npad_live, width, T(-1), T(1),
                                              2, 0, 0, 0, 0, ss, d_tilemap + tri64_off, tri64_count);
-        else if (kIsF32 && opt_mfma && (opt_split_where & (ss == stream_b ? 2 : 1)))   // half tiles: the 128 x 128 MFMA kernel only
+        else if (kIsF32 && opt_mfma && ss != stream_b)   // half tiles at the end of the list: the launch on every CU only (128 x 128 MFMA kernel)
           gemm<ROLE_DOWNDATE, false>(d_V + c0, ldy, d_V + c0, ldy, S(), ld, npad_live, npad_live, width, T(-1), T(1), 2, 0,
                                      0, 0, 0, ss, d_tilemap + trih_off, trih_count);
         else
@@ -1570,15 +1403,6 @@ struct Filter : FilterBase {
     acc += d[0] + d[8] + d[16];                          // vR.cpp:854
     acc += d[32] + d[40] + d[48] + d[24];                // vR.cpp:855
     *out = double(acc);
-    return EKF_OK;
-  }
-  int flow_trace(unsigned long long* out, int max_tasks, int* ntasks) override {
-    HIPCHK(hipSetDevice(device));
-    if (ntasks) *ntasks = flow_ntasks;
-    if (!d_flow_trace || !out) return EKF_OK;
-    HIPCHK(hipStreamSynchronize(stream));
-    const int cnt = std::min(max_tasks, flow_ntasks);
-    HIPCHK(hipMemcpy(out, d_flow_trace, (size_t)cnt * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return EKF_OK;
   }
   int check_invariants(double* pad, double* asym, double* big) override {
@@ -2049,7 +1873,6 @@ struct Filter : FilterBase {
       sh_list.assign(idx, idx + M);
       HIPCHK(hipMemcpyAsync(d_midx, sh_list.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice, stream));
     }
-    sh_list.clear();
     const T* d_zz = static_cast<const T*>(dz);
     const int nb = NB();
     const int m = 2 * M + (plane ? 3 : 0), m_pad = round_up(m, nb);
@@ -2057,6 +1880,11 @@ struct Filter : FilterBase {
     T* nu_row = d_W + (size_t)ldy * npad_live;
     if (w_zeroed_n != n) {
       HIPCHK(hipMemsetAsync(d_W + (size_t)n * ldy, 0, (size_t)(npad_live - n + nb) * ldy * sizeof(T), stream));
+      // the pad rows [n, npad_live) of V are the B operand of every rank's downdate, but only the rank whose tile-padded
+      // panel reaches them ever solves them: everywhere else they must be cleared when n shrinks, or rows gathered in
+      // earlier frames would be subtracted into the zero padding of Sigma
+      if (npad_live > n)
+        HIPCHK(hipMemsetAsync(d_V + (size_t)n * ldy, 0, (size_t)(npad_live - n) * ldy * sizeof(T), stream));
       w_zeroed_n = n;
     }
     // own state rows, and the tile-padded panel [p0, p0 + prows) the tile GEMMs run on: it covers the own rows and,
@@ -2445,10 +2273,6 @@ int ekf_set_sigma_block(ekf_filter* f, const void* in, int r0, int c0, int rows,
   return f->impl->set_sigma(in, r0, c0, rows, cols);
 }
 int ekf_covariance_parameter(ekf_filter* f, double* out) { IMPL_OR_ARG(f); if (!out) return EKF_ERR_ARG; return f->impl->covariance_parameter(out); }
-int ekf_debug_flow_trace(ekf_filter* f, unsigned long long* out, int max_tasks, int* ntasks) {
-  IMPL_OR_ARG(f);
-  return f->impl->flow_trace(out, max_tasks, ntasks);
-}
 int ekf_check_invariants(ekf_filter* f, double* pad, double* asym, double* big) { IMPL_OR_ARG(f); return f->impl->check_invariants(pad, asym, big); }
 int ekf_feature_xyz(ekf_filter* f, int index, void* xyz, void* cov) { IMPL_OR_ARG(f); return f->impl->feature_xyz(index, xyz, cov); }
 

@@ -18,7 +18,7 @@ namespace ekf {
 // ---------------------------------------------------------------------------------------
 // nu = z - h for the measured list (+ plane rows: 0 - mu[{1,4,6}], vR.cpp:1257-1260).
 // ---------------------------------------------------------------------------------------
-constexpr int kQueueCounters = 256;              // 8 heads (one per XCD) x up to 32 queued launches per update
+constexpr int kQueueCounters = 256;              // work-queue heads of the queued launches of one update (8 ints apart)
 
 // A measured list read from DEVICE memory (ekf_update_device) cannot be checked on the host: an entry outside
 // [0, nfeat) or a list that is not strictly ascending raises status[1] (the next synchronising call returns
@@ -245,11 +245,6 @@ struct GemmArgs {
   const void* B2; int ldb2;
   void* C2; int ldc2;
   int n2, nr2;
-  // XCD-aware queue (xcd_queues != 0; counter then points at 8 heads): the list is cut into 8 equal runs, run q
-  // served first to the workgroups of XCD q (workgroup w runs on XCD w % 8); a workgroup whose run is exhausted
-  // moves on to the next runs.  The tiles in flight on an XCD are then neighbours in the list -- a super-tile of the
-  // downdate -- and share their operand panels in that XCD's L2 instead of fetching them into all eight.
-  int xcd_queues;
 };
 constexpr int kSecondProduct = 0x10000;         // flag on bj for a tile of the second product
 constexpr int kHalfTile = 0x20000;              // flag on bi: 64-row half tile, bi & 0xffff in 64-row units (k_gemm_mfma, downdate)
@@ -264,19 +259,7 @@ __device__ __forceinline__ bool gemm_next_tile(const GemmArgs& g, int* s_tile, i
   }
   __syncthreads();                       // everyone is done with the previous tile (and s_tile)
   if (threadIdx.x == 0) {
-    int t = g.ntiles;
-    if (!g.xcd_queues) {
-      t = atomicAdd(g.counter, 1);
-    } else {
-      const int q0 = blockIdx.x & 7;
-      for (int d = 0; d < 8; ++d) {
-        const int q = (q0 + d) & 7;
-        const int lo = (int)((long long)g.ntiles * q / 8), hi = (int)((long long)g.ntiles * (q + 1) / 8);
-        const int i = atomicAdd(g.counter + q, 1);
-        if (lo + i < hi) { t = lo + i; break; }
-      }
-    }
-    *s_tile = t;
+    *s_tile = atomicAdd(g.counter, 1);
   }
   __syncthreads();
   const int t = *s_tile;
@@ -394,18 +377,17 @@ __device__ unsigned long long ekf_loop_buf[8 * 1024];    // inside the K loop (E
 #define EKF_LOOP_STAMP(var) do { } while (0)
 #endif
 
-template <int ROLE, bool BT, int TM = 128, int TN = 128, int NW = 4>
-// Register budget: two 128 x 128 workgroups per CU (NW / 2 waves per SIMD each); the 64 x 64 chain tiles (ROLE_TRAILING)
+template <int ROLE, bool BT, int TM = 128, int TN = 128>
+// Register budget: two 128 x 128 workgroups per CU (two waves per SIMD each); the 64 x 64 chain tiles (ROLE_TRAILING)
 // are held to 80 registers so that one of them fits on a CU BESIDE two downdate workgroups (2 x 216 + 80 <= 512, LDS
 // 2 x 64 + 32 KiB): the trailing update of the chain then runs on every CU, not only on the ones the second stream leaves.
-__global__ void __launch_bounds__(64 * NW, (ROLE == ROLE_TRAILING && TM == 64 && TN == 64) ? 6 : NW / 2) k_gemm_mfma(GemmArgs g) {
+__global__ void __launch_bounds__(256, (ROLE == ROLE_TRAILING && TM == 64 && TN == 64) ? 6 : 2) k_gemm_mfma(GemmArgs g) {
   // TM x TN output tile (64 or 128 each), 4 waves as 2 x 2, each wave (TM/2) x (TN/2) = MI x NJ
   // accumulators of 32x32.  The small shapes exist for the latency-bound launches (chain tiles, tail of
   // the triangular solve): same flop, 2-4x the workgroups.
-  // NW = 4 waves as 2 x 2 (each (TM/2) x (TN/2)) or NW = 8 waves as 2 x 4 (each (TM/2) x (TN/4); NT mode, TN = 128):
-  // four waves per SIMD instead of two to hide the barrier / LDS / global latency of each other.
-  constexpr int NT = 64 * NW, WC = NW / 2, BK = 32, NQ = BK / 4, NJ = TN / (32 * WC), PB = TN * 8 / NT;
-  static_assert(NW == 4 || (NW == 8 && TN == 128), "eight waves: 128 columns");
+  // (eight-wave workgroups, 2 x 4 waves of (TM/2) x (TN/4), were 3-5 % faster per launch alone and nothing in the step:
+  // removed in round 3)
+  constexpr int NT = 256, WC = 2, BK = 32, NQ = BK / 4, NJ = TN / (32 * WC), PB = TN * 8 / NT;
   // a queued downdate launch may carry HALF tiles (64 x 128, kHalfTile on bi, bi then in 64-row units) at the end of
   // its list: the last jobs of the slower workgroups are half as long, and the launch ends more evenly
   constexpr bool SPLIT = (ROLE == ROLE_DOWNDATE) && !BT && TM == 128 && TN == 128;
@@ -579,7 +561,7 @@ __global__ void __launch_bounds__(64 * NW, (ROLE == ROLE_TRAILING && TM == 64 &&
         store_tile(stage ^ 1);
         if (more2) load_tile(k0 + 2 * BK);
 #ifndef EKF_NO_SGB
-        if constexpr (more && more2 && NW == 4 && !BT && TN == 128) {
+        if constexpr (more && more2 && !BT && TN == 128) {
           // steady state: one ds_write after every few MFMAs of this group instead of all of them in a row behind it
           // (the stores wait for their global loads one by one; in a row they leave the matrix pipe with one
           // instruction in flight).  128 x 128 NT tile: alone on a CU a K = 1024 tile 85.8 -> 79.1 us, the 1128-tile

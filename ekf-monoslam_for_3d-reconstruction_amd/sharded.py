@@ -307,9 +307,9 @@ def bench(pkg, cfg, n_feat, px0, z, args, rank, world, dev):
     import torch
     import torch.distributed as dist
     import bench as _bench
-    # a map runs `seg` frames (bench.segment_frames: the fp32 covariance of a map whose features are ALL measured in
-    # EVERY frame stops being positive after a few hundred frames); longer runs continue on a map started afresh
-    # from the stream's current pixels -- all maps are built before the clock starts
+    # a map runs `seg` frames (bench.segment_frames: the run lengths over which the fp32 covariance was VERIFIED to stay
+    # positive with every feature measured in every frame); longer runs continue on a map started
+    # afresh from the stream's current pixels -- all maps are built before the clock starts
     seg = _bench.segment_frames(n_feat)
     frames = args.warmup + args.steps
     nseg = max(1, -(-frames // seg))
@@ -391,8 +391,10 @@ def bench(pkg, cfg, n_feat, px0, z, args, rank, world, dev):
         "config": {"workload": f"N={n_feat} inverse-depth features, n={n}, M=N measured per frame, fp32, "
                                f"row-panel shard over {world} GPUs (BASELINE configs[3])",
                    "features": n_feat, "state_dim": n, "measured_per_frame": n_feat,
-                   "parallelism": f"row-panel shard x{world}: all-gather H, S, V over RCCL, chunk-pipelined beside the "
-                                  "replicated Cholesky chain",
+                   "parallelism": f"row-panel shard x{world}: all-gather H, S, V over "
+                                  f"{'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend() + ' (host staging, functional rehearsal)'}"
+                                  ", chunk-pipelined beside the replicated Cholesky chain",
+                   "backend": dist.get_backend(),
                    "frames_per_map": seg, "maps": nseg},
         "run_sane": sane,
         "rank0_rows": [info.row_begin, info.row_end],

@@ -157,9 +157,10 @@ int ekf_get_predictions(ekf_filter* f, void* h, unsigned char* visible,
  * is the measured set, z holds 2 pixels per listed feature.  plane_constraint != 0 appends
  * the forsePlane pseudo-measurement (vR.cpp:1250-1263, 1272).  M = 0 and no plane: no-op.
  * A factorisation of St that meets a non-positive pivot is reported as EKF_ERR_NUMERIC by the next
- * synchronising call (ekf_synchronize, any getter).  With fp32 this is where a map ends up whose features are
- * ALL measured in EVERY frame for hundreds of frames (the formulation keeps no square root and the features
- * carry no process noise: N = 1000 after ~780 frames, N = 200 after ~5400); an EKF_F64 filter does not. */
+ * synchronising call (ekf_synchronize, any getter).  (Through most of round 2 an fp32 map whose features were ALL
+ * measured in EVERY frame ended there after a few hundred frames; the cause -- partial sums rounded at the magnitude
+ * of Sigma -- was fixed, see EKF_OPT_FEATURE_NOISE above and DESIGN.md section 8: the fp32 covariance now stays
+ * positive over every run followed so far.) */
 int ekf_update(ekf_filter* f, const void* z, const int* indices, int M, int plane_constraint);
 /* Same with z (2 M scalars) and indices (M ints) already resident in DEVICE memory.  Contract:
  *  - both buffers are read IN PLACE and ASYNCHRONOUSLY by the kernels of the queued step: they must stay allocated
@@ -267,9 +268,6 @@ int ekf_get_sigma_block(ekf_filter* f, void* out, int r0, int c0, int rows, int 
 int ekf_set_sigma_block(ekf_filter* f, const void* in, int r0, int c0, int rows, int cols);
 /* Covariance_Parameter (vR.cpp:841-866): trace of Sigma[0:7,0:7]. */
 int ekf_covariance_parameter(ekf_filter* f, double* out);
-/* Diagnostic (EKF_FLOW_TRACE=1 in the environment of ekf_create): per task of the last update's persistent dataflow
- * launch 4 words -- fetched, inputs ready, stored (100 MHz ticks), workgroup | type << 32.  tools/flow_trace.py. */
-int ekf_debug_flow_trace(ekf_filter* f, unsigned long long* out, int max_tasks, int* ntasks);
 /* Invariants of the device-resident covariance, evaluated on the device (no n^2 copy): max |Sigma| outside the live
  * n x n inside the padded buffer (the tile kernels rely on exact zeros there), max |Sigma[i][j] - Sigma[j][i]| and
  * max |Sigma[i][j]| over the live block (the reference never symmetrises, vR.cpp:1279; this implementation keeps

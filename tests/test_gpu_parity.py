@@ -741,38 +741,10 @@ def test_fused_wupdate_launch_is_bit_identical(monkeypatch):
         assert np.array_equal(mu, outs[0][0]) and np.array_equal(S, outs[0][1])
 
 
-def test_dataflow_launch_is_bit_identical(monkeypatch):
-    """EKF_FLOW=1 (opt-in, csrc/ekf_flow.hpp): every solve / W-update / downdate tile of an update in ONE persistent
-    launch with device-side dependencies (release / acquire hand-offs between workgroups, bounded waits).  Same tiles,
-    same arithmetic per tile: mu and Sigma must equal the launch-per-phase path to the last bit, over several frames."""
-    from __graft_entry__ import load_package
-    pkg = load_package()
-    from ekf_monoslam_amd import synthetic
-    cfg = pkg.kinect_config()
-    n_feat = 640                                             # 10 block steps, chunks 3 / 6 / 10, 465 lower tiles >= 256 CUs
-    px0, z = synthetic.measurement_stream(cfg, n_feat, 4, sigma_px=0.5)
-    idx = np.arange(n_feat, dtype=np.int32)
-    outs = []
-    for mode in ("0", "1"):
-        monkeypatch.setenv("EKF_FLOW", mode)                 # read when the filter is created
-        f = pkg.VSlamFilter(cfg, capacity_features=n_feat)
-        f.setDt(1.0 / 30.0)
-        for (u, v) in px0:
-            assert f.addFeature((u, v)) == 1
-        for k in range(3):
-            f.predict()
-            f.update(z[k].reshape(-1), idx)
-        f.synchronize()                                      # raises if a wait inside the launch timed out
-        outs.append((f.getFullState(), f.getFullSigma()))
-    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
-
-
 @pytest.mark.parametrize("knobs", [
     {"EKF_SPLIT_TAIL": "0"},                                     # no half tiles at the end of the downdate's list
-    {"EKF_SPLIT_TAIL": "200", "EKF_SPLIT_WHERE": "3"},           # half tiles on the main AND the second stream
-    {"EKF_GEMM_WAVES": "8"},                                     # 128 x 128 tiles on eight-wave workgroups
+    {"EKF_SPLIT_TAIL": "200"},                                   # another number of half tiles
     {"EKF_FUSE_WU": "0"}, {"EKF_FUSE_WU": "2"},                  # W update and downdate never / always in one launch
-    {"EKF_XCD_QUEUES": "1"},                                     # one queue head per XCD
 ])
 def test_launch_structure_knobs_are_bit_identical(monkeypatch, knobs):
     """The tuning knobs of DESIGN.md section 3 change WHICH workgroup computes a tile and in what tile shape, never the
@@ -786,7 +758,7 @@ def test_launch_structure_knobs_are_bit_identical(monkeypatch, knobs):
     idx = np.arange(n_feat, dtype=np.int32)
     outs = []
     for env in ({}, knobs):
-        for k in ("EKF_SPLIT_TAIL", "EKF_SPLIT_WHERE", "EKF_GEMM_WAVES", "EKF_FUSE_WU", "EKF_XCD_QUEUES"):
+        for k in ("EKF_SPLIT_TAIL", "EKF_FUSE_WU"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)                             # read when the filter is created

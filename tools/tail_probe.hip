@@ -53,15 +53,14 @@ int main() {
       if (nsplit == 0 || nsplit == 256) {
         hipMemset(S2, 0, (size_t)(n + 128) * ld * 4);
         GemmArgs a{V, ldy, V, ldy, S2, ld, 640, -1.0, 1.0, 2, 0, 0, 0, 0, dtl, ntl, counters + (cn++ % 60000), 0, 0, 1};
-        if (nsplit) k_gemm_mfma<ROLE_DOWNDATE, false, 128, 128, 8><<<512, 512>>>(a);
-        else k_gemm_mfma<ROLE_DOWNDATE, false><<<512, 256>>>(a);
+        k_gemm_mfma<ROLE_DOWNDATE, false><<<512, 256>>>(a);
         hipMemcpy((nsplit ? r1 : r0).data(), S2, r0.size() * 4, hipMemcpyDeviceToHost);
         if (nsplit) {
           size_t bad = 0; for (size_t i = 0; i < r0.size(); ++i) bad += (r0[i] != r1[i]);
           printf("split list vs plain list: %zu differing elements of %zu\n", bad, r0.size());
         }
       }
-      for (int K : {384, 640, 1024}) for (int wgs : {512, 448}) for (int nw : {4, 8}) {
+      for (int K : {384, 640, 1024}) for (int wgs : {512, 448}) for (int nw : {4}) {
         float best = 1e9;
         for (int pass = 0; pass < 3; ++pass) {
           const int reps = 20;
@@ -69,8 +68,7 @@ int main() {
           hipEventRecord(ea);
           for (int r = 0; r < reps; ++r) {
             GemmArgs a{V, ldy, V, ldy, S, ld, K, -1.0, 1.0, 2, 0, 0, 0, 0, dtl, ntl, counters + (cn++ % 60000), 0, 0, 1};
-            if (nw == 8) k_gemm_mfma<ROLE_DOWNDATE, false, 128, 128, 8><<<std::min(ntl, wgs), 512>>>(a);
-            else k_gemm_mfma<ROLE_DOWNDATE, false><<<std::min(ntl, wgs), 256>>>(a);
+            k_gemm_mfma<ROLE_DOWNDATE, false><<<std::min(ntl, wgs), 256>>>(a);
           }
           hipEventRecord(eb); hipEventSynchronize(eb);
           float ms; hipEventElapsedTime(&ms, ea, eb); best = std::min(best, ms / reps);
