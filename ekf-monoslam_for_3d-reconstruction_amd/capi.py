@@ -73,6 +73,10 @@ _PROTOS = {
     "ekf_get_blur_predictions": (C.c_int, [_P, _P]),
     "ekf_find_matches": (C.c_int, [_P, C.c_double, _P, _P, _P]),
     "ekf_export_points": (C.c_int, [_P, _P, C.c_int]),
+    "ekf_export_points_table": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
+    "ekf_get_feature_ids": (C.c_int, [_P, _P, _P]),
+    "ekf_set_feature_meta": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    "ekf_num_archived": (C.c_int, [_P]),
     "ekf_get_search_ellipses": (C.c_int, [_P, C.c_int, _P]),
     "ekf_ransac_1point": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, _P, _P, C.POINTER(C.c_int)]),
     "ekf_update_two_stage": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_uint, C.c_double, C.c_double, _P, _P,

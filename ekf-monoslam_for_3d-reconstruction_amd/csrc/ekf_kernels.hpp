@@ -720,13 +720,18 @@ __global__ void k_ransac_count(const unsigned char* __restrict__ mask, int M, in
 // The reference fills rows of XYZ features only (inverse-depth rows stay zero, :360-375); with
 // `convert_inverse_depth` those rows get inverseDepth2XyzWorld(f) and Jf Sigma_ff Jf^T instead
 // (what its marker code does, :171-183).
+// row_of != nullptr: feature i goes to row row_of[i] of a table of `rows` rows (Patch::real_index order,
+// RosVSLAMRansac.cpp:361, 388); rows outside the table are skipped.
 template <typename T>
 __global__ void k_export_points(const T* __restrict__ mu, const T* __restrict__ S, int ld,
                                 const int* __restrict__ pos, const int* __restrict__ coding, int N,
-                                T map_scale, int convert_inverse_depth, T* __restrict__ out) {
+                                T map_scale, int convert_inverse_depth, T* __restrict__ out,
+                                const int* __restrict__ row_of = nullptr, int rows = 0) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  T* o = out + (size_t)i * 12;
+  const int row = row_of ? row_of[i] : i;
+  if (row_of && (row < 0 || row >= rows)) return;
+  T* o = out + (size_t)row * 12;
   const int p = pos[i];
   if (coding[i] != 0) {
     for (int k = 0; k < 3; ++k) o[k] = mu[p + k] * map_scale;
@@ -761,6 +766,32 @@ __global__ void k_export_points(const T* __restrict__ mu, const T* __restrict__ 
       for (int k = 0; k < 6; ++k) acc += JS[a * 6 + k] * J[b * 6 + k];
       o[3 + a * 3 + b] = acc;
     }
+}
+
+// removeFeature's "segment to save good features" (vR.cpp:394-404): XYZ_pos = mu[pos:pos+3] and cov_4_delete = the 3x3
+// block of Sigma row by row, of the listed state positions, captured BEFORE the compaction pass drops them.
+template <typename T>
+__global__ void k_archive_points(const T* __restrict__ mu, const T* __restrict__ S, int ld,
+                                 const int* __restrict__ state_pos, int count, T* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t / 12, e = t % 12;
+  if (i >= count) return;
+  const int p = state_pos[i];
+  out[(size_t)i * 12 + e] = (e < 3) ? mu[p + e] : S[(size_t)(p + (e - 3) / 3) * ld + p + (e - 3) % 3];
+}
+
+// The archived patches written over their rows of the points table (RosVSLAMRansac.cpp:406-414): XYZ_pos * map_scale
+// and cov_4_delete.
+template <typename T>
+__global__ void k_export_archived(const T* __restrict__ arch, const int* __restrict__ row_of, int count, T map_scale,
+                                  T* __restrict__ out, int rows) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t / 12, e = t % 12;
+  if (i >= count) return;
+  const int row = row_of[i];
+  if (row < 0 || row >= rows) return;
+  const T v = arch[(size_t)i * 12 + e];
+  out[(size_t)row * 12 + e] = (e < 3) ? v * map_scale : v;
 }
 
 // High-innovation gate (vR.cpp:1113-1114): (h - z)^T S_hi^-1 (h - z) <= thr with S_hi = H Sigma H^T

@@ -238,6 +238,29 @@ class VSlamFilter:
         self._check(self._lib.ekf_export_points(self._h, self._ptr(out), int(bool(convert_inverse_depth))))
         return out
 
+    def getPointsTable(self):
+        """RosVSLAM::getPointsFeatures in the reference's own layout (RosVSLAMRansac.cpp:340-418): rows indexed by
+        Patch::real_index, the patches archived at removal (vR.cpp:394-404) included -- what `points.txt` holds."""
+        rows = C.c_int(0)
+        self._check(self._lib.ekf_export_points_table(self._h, None, 0, C.byref(rows)))
+        out = np.zeros((rows.value, 12), self.dtype)
+        if rows.value:
+            self._check(self._lib.ekf_export_points_table(self._h, self._ptr(out), rows.value, C.byref(rows)))
+        return out
+
+    def featureIds(self):
+        """(real_index, n_find) per live feature: Patch::real_index / Patch::n_find."""
+        N = self.numOfFeatures()
+        ri, nf = np.zeros(N, np.int32), np.zeros(N, np.int32)
+        self._check(self._lib.ekf_get_feature_ids(self._h, self._ptr(ri), self._ptr(nf)))
+        return ri, nf
+
+    def setFeatureMeta(self, index: int, real_index: int = -1, n_find: int = -1):
+        self._check(self._lib.ekf_set_feature_meta(self._h, int(index), int(real_index), int(n_find)))
+
+    def numArchived(self) -> int:
+        return int(self._lib.ekf_num_archived(self._h))
+
     def searchEllipses(self, sigma_size: Optional[int] = None):
         """computeEllipsoidParameters (vR.cpp:1368-1382): (N,3) ints (a, b, theta_deg) per feature."""
         N = self.numOfFeatures()

@@ -282,6 +282,23 @@ int ekf_feature_xyz(ekf_filter* f, int index, void* xyz, void* cov3x3);
  * 3x3 covariance block row by row.  The reference fills the rows of XYZ features only; with
  * convert_inverse_depth != 0 the inverse-depth rows carry inverseDepth2XyzWorld(f) and Jf Sigma Jf^T. */
 int ekf_export_points(ekf_filter* f, void* out, int convert_inverse_depth);
+/* The same table in the reference's own layout (RosVSLAMRansac.cpp:340-418): rows indexed by Patch::real_index --
+ * (real_index of the LAST live feature) + 1 rows (:350-352), ROW-MAJOR rows x 12 --, live XYZ features at their rows,
+ * live inverse-depth rows zero, then the patches ARCHIVED at removal written over their rows (:406-414): a removed
+ * XYZ feature with n_find > 5 leaves XYZ_pos and the 3x3 block of Sigma of the moment of its removal behind
+ * (deleted_patches, vR.cpp:394-404; captured on the device by ekf_remove_feature(s)).  The archive is emptied by the
+ * call that finds more than 7000 entries in it (:396-404).  *rows receives the row count; out == NULL only queries it;
+ * max_rows < rows is EKF_ERR_ARG.  An archived patch whose real_index lies beyond the table is skipped (the reference
+ * writes out of bounds there). */
+int ekf_export_points_table(ekf_filter* f, void* out, int max_rows, int* rows);
+/* Patch::real_index (vR.cpp:148, 318-319: 1, 2, ... in creation order, never reused) and Patch::n_find (Patch.cpp:86,
+ * 145: 1 at creation, +1 per ekf_update_two_stage in which the feature is a low- or high-innovation inlier) per live
+ * feature; either pointer may be NULL.  ekf_update (the bare update block) does not touch n_find: a caller that
+ * composes its own flow keeps it with ekf_set_feature_meta (a negative value leaves that field alone). */
+int ekf_get_feature_ids(const ekf_filter* f, int* real_index, int* n_find);
+int ekf_set_feature_meta(ekf_filter* f, int index, int real_index, int n_find);
+/* deleted_patches.size() */
+int ekf_num_archived(const ekf_filter* f);
 
 /* Per-kernel HIP-event timing (EKF_OPT_PROFILE).  Kernel ids are dense in
  * [0, ekf_profile_kernels()). */

@@ -357,6 +357,8 @@ class Feature:
     Hc: Optional[np.ndarray] = None  # 2x7   (compact: columns 0..6 of the dense 2xn row pair)
     Hf: Optional[np.ndarray] = None  # 2x6 or 2x3 (columns pos..pos+size)
     z: Optional[np.ndarray] = None
+    real_index: int = 0              # Patch::real_index = patchnumbre at creation (Patch.cpp:84, vR.cpp:318-319)
+    n_find: int = 1                  # Patch::n_find (Patch.cpp:86), +1 per update in which the patch is in Li or Hi (:145)
 
     @property
     def size(self) -> int:
@@ -401,6 +403,8 @@ class DenseFilter:
         S[10:13, 10:13] = sv * sv * np.eye(3, dtype=T)
         self.Sigma = S
         self.features: List[Feature] = []
+        self.patchnumbre = 1                                    # vR.cpp:148
+        self.deleted_patches = []                               # (real_index, XYZ_pos (3), cov_4_delete (9)), vR.cpp:394-404
         self.St = None
         self.Kt = None
         self.Ft = None
@@ -450,6 +454,12 @@ class DenseFilter:
         Jp = J_f_hW @ Rot @ J_undist              # vR.cpp:359
         return f, G, Jp
 
+    def _new_feature(self, pos):
+        """Patch(..., pos, patchnumbre); patchnumbre += 1 (vR.cpp:318-319)."""
+        ft = Feature(position_in_state=pos, coding=INV, real_index=self.patchnumbre)
+        self.patchnumbre += 1
+        return ft
+
     def add_feature(self, u, v) -> int:
         T = self.T
         parts = self._add_feature_parts(u, v)
@@ -457,7 +467,7 @@ class DenseFilter:
             return 0
         f, G, Jp = parts
         nOld = self.n
-        self.features.append(Feature(position_in_state=nOld, coding=INV))
+        self.features.append(self._new_feature(nOld))
         self.mu = np.concatenate([self.mu, f])
         Js = np.zeros((nOld + 6, nOld + 3), dtype=T)
         Js[:nOld, :nOld] = np.eye(nOld, dtype=T)
@@ -474,6 +484,11 @@ class DenseFilter:
     def remove_feature(self, index):
         p = self.features[index]
         pos, psize = p.position_in_state, p.size
+        if p.n_find > 5 and psize == 3:                                   # "a segment to save good features", vR.cpp:394-404
+            # XYZ_pos = inverseDepth2XyzWorld(3-vector) = the vector itself (:699-700); cov_4_delete(i) = the transposed
+            # 3x3 block in Eigen's column-major linear order = the block row by row
+            self.deleted_patches.append((p.real_index, self.mu[pos:pos+3].copy(),
+                                         self.Sigma[pos:pos+3, pos:pos+3].reshape(-1).copy()))
         keep = np.r_[0:pos, pos+psize:self.n]
         self.mu = self.mu[keep]
         self.Sigma = self.Sigma[np.ix_(keep, keep)]
@@ -721,6 +736,34 @@ class DenseFilter:
         return y, J @ self.Sigma[pos:pos+6, pos:pos+6] @ J.T
 
 
+def get_points_features(filt):
+    """RosVSLAM::getPointsFeatures (RosVSLAMRansac.cpp:340-418), the table behind points.txt: rows indexed by
+    Patch::real_index, (real_index of the LAST live patch) + 1 of them (:350-352); live XYZ features carry
+    [X Y Z] * map_scale and their 3x3 covariance block row by row (:376-388), live inverse-depth rows stay zero
+    (:363-375); then the patches archived at removal are written over their rows (:406-414), and the archive is
+    cleared once it holds more than 7000 entries (:396-404).  An archived patch whose real_index lies beyond the
+    table (the reference would write out of bounds there) is skipped."""
+    T = filt.T
+    if not filt.features:
+        return np.zeros((0, 12), dtype=T)
+    scale = filt.mu[13] if filt.camera_dim == 14 else T(1)
+    rows = filt.features[-1].real_index + 1
+    pts = np.zeros((rows, 12), dtype=T)
+    for ft in filt.features:
+        if ft.coding != XYZ:
+            continue
+        p = ft.position_in_state
+        pts[ft.real_index, 0:3] = filt.mu[p:p+3] * scale
+        pts[ft.real_index, 3:12] = filt.Sigma[p:p+3, p:p+3].reshape(-1)
+    for (ri, xyz, cov) in filt.deleted_patches:
+        if ri < rows:
+            pts[ri, 3:12] = cov
+            pts[ri, 0:3] = xyz * scale
+    if len(filt.deleted_patches) > 7000:
+        filt.deleted_patches.clear()
+    return pts
+
+
 def ellipse_parameters(St, sigma_size):
     """computeEllipsoidParameters, vR.cpp:1368-1382, for one 2x2 block: (a, b, theta_deg) ints.
     SelfAdjointEigenSolver returns ascending eigenvalues; the sign of its eigenvectors is not
@@ -861,6 +904,9 @@ def update_two_stage(filt, z, indices, plane=False, seed=0, threshold=None, chi2
     if hi.any() or plane:
         sel_i = [indices[k] for k in range(M) if hi[k]]
         filt.update(z[hi].reshape(-1), sel_i, plane=plane)                             # :1245-1284
+    for k in range(M):                                                                 # update_quality_index, :1297, Patch.cpp:145
+        if li[k] or hi[k]:
+            filt.features[indices[k]].n_find += 1
     return li, hi, drawn
 
 
@@ -877,7 +923,7 @@ class StructuredFilter(DenseFilter):
             return 0
         f, G, Jp = parts
         n = self.n
-        self.features.append(Feature(position_in_state=n, coding=INV))
+        self.features.append(self._new_feature(n))
         self.mu = np.concatenate([self.mu, f])
         S = np.empty((n+6, n+6), dtype=T)
         S[:n, :n] = self.Sigma
@@ -889,6 +935,40 @@ class StructuredFilter(DenseFilter):
         S[n:, n:] = C
         self.Sigma = S
         return 1
+
+    def add_features(self, pixels) -> int:
+        """`add_feature` for a list of pixels, in order, on ONE preallocated covariance (the sequential form copies the
+        growing matrix once per feature: 1000 adds at n = 6014 move ~100 GB).  Same expressions on the same operands as
+        `add_feature` -- rows n.. = G Sigma[0:7, :n], corner = G Sigma_cc G^T + sigma_px^2 Jp Jp^T (+ sigma_rho_0) --
+        so the result is bit-identical to the sequential adds (tests/test_oracle_flavours.py).  Returns the number
+        of features added (pixels outside the image are skipped, as `add_feature` returning 0)."""
+        T = self.T
+        pixels = [tuple(p) for p in pixels]
+        n0 = self.n
+        cap = n0 + 6 * len(pixels)
+        S = np.zeros((cap, cap), dtype=T)
+        S[:n0, :n0] = self.Sigma
+        mu = np.zeros(cap, dtype=T)
+        mu[:n0] = self.mu
+        n = n0
+        added = 0
+        for (u, v) in pixels:
+            parts = self._add_feature_parts(u, v)        # reads mu[0:7] only: unchanged by the adds
+            if parts is None:
+                continue
+            f, G, Jp = parts
+            self.features.append(self._new_feature(n))
+            mu[n:n+6] = f
+            S[n:n+6, :n] = G @ S[0:7, :n]
+            S[:n, n:n+6] = S[:n, 0:7] @ G.T
+            C = G @ S[0:7, 0:7] @ G.T + T(self.sigma_pixel_2) * (Jp @ Jp.T)
+            C[5, 5] += T(np.float32(self.cfg.sigma_rho_0))
+            S[n:n+6, n:n+6] = C
+            n += 6
+            added += 1
+        self.mu = mu[:n].copy()
+        self.Sigma = S[:n, :n].copy()
+        return added
 
     def predict_covariance(self, Ft, Q):
         S = self.Sigma
@@ -1090,14 +1170,18 @@ def synthetic_measurements(filt: DenseFilter, indices, seed: int = 1235, sigma=N
 
 
 def build_scenario(flavour, cfg: Config, n_features: int, dtype=np.float32, seed=1234,
-                   v=(0.3, 0.0, 0.0), w=(0.0, 0.05, 0.0), dT=1.0/30.0, camera_dim=STATE_DIM):
+                   v=(0.3, 0.0, 0.0), w=(0.0, 0.05, 0.0), dT=1.0/30.0, camera_dim=STATE_DIM, batched_add=False):
     """Initial state of SURVEY 8d: mu0/Sigma0 of the constructor, constant velocity set in mu,
     N features inserted through the add-feature math in order."""
     filt = flavour(cfg, dtype, camera_dim)
     filt.dT = dT
     filt.mu[7:10] = np.asarray(v, dtype=filt.T)
     filt.mu[10:13] = np.asarray(w, dtype=filt.T)
-    for (pu, pv) in synthetic_pixels(cfg, n_features, seed):
+    px = synthetic_pixels(cfg, n_features, seed)
+    if batched_add and hasattr(filt, "add_features"):
+        assert filt.add_features(px) == n_features
+        return filt
+    for (pu, pv) in px:
         ok = filt.add_feature(pu, pv)
         assert ok == 1
     return filt

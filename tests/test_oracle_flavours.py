@@ -32,6 +32,28 @@ def test_dense_matches_structured(dtype, tol, n_feat):
     assert relf(a.Kt, b.Kt) < tol * 50
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_batched_add_is_the_sequential_add(dtype):
+    """`StructuredFilter.add_features` (one preallocated covariance; what the N = 1000 parity tests build their oracle
+    with) against N sequential `add_feature` calls, and against the reference-shaped dense add (Js S' Js^T): bit-identical
+    to the former, to rounding equal to the latter.  A pixel outside the image is skipped by both."""
+    cfg = o.Config.kinect()
+    a = o.build_scenario(o.StructuredFilter, cfg, 50, dtype)
+    b = o.build_scenario(o.StructuredFilter, cfg, 50, dtype, batched_add=True)
+    assert np.array_equal(a.mu, b.mu) and np.array_equal(a.Sigma, b.Sigma)
+    assert [f.position_in_state for f in a.features] == [f.position_in_state for f in b.features]
+    d = o.build_scenario(o.DenseFilter, cfg, 50, dtype)
+    assert relf(b.Sigma, d.Sigma) < (1e-12 if dtype == np.float64 else 2e-6)
+    px = list(o.synthetic_pixels(cfg, 5)) + [(1.0, 1.0)] + list(o.synthetic_pixels(cfg, 3, seed=9))
+    c1, c2 = o.StructuredFilter(cfg, dtype), o.StructuredFilter(cfg, dtype)
+    n1 = sum(c1.add_feature(u, v) for (u, v) in px)
+    assert c2.add_features(px) == n1 == 8
+    assert np.array_equal(c1.Sigma, c2.Sigma) and np.array_equal(c1.mu, c2.mu)
+    # further adds on top of a batched map (what the resize tests do)
+    assert a.add_feature(100.0, 100.0) == 1 and b.add_feature(100.0, 100.0) == 1
+    assert np.array_equal(a.Sigma, b.Sigma)
+
+
 def test_dense_matches_structured_n200_single_frame():
     a = run(o.DenseFilter, np.float64, 200, frames=1)
     b = run(o.StructuredFilter, np.float64, 200, frames=1)

@@ -176,3 +176,33 @@ def test_glibc_rand_matches_the_c_library():
         want = [libc.rand() for _ in range(400)]
         g = o.GlibcRand(seed)
         assert [g.rand() for _ in range(400)] == want
+
+
+def test_points_table_layout_known_answer():
+    """getPointsFeatures (RosVSLAMRansac.cpp:340-418) from the source alone: real_index counts from 1 (vR.cpp:148,
+    318-319), the table has (real_index of the last live patch) + 1 rows (:350-352), inverse-depth rows are zero
+    (:363-375), an XYZ row is [mu * map_scale | the 3x3 block row by row] (:376-388), and a removed XYZ patch with
+    n_find > 5 keeps the values of the moment of its removal (vR.cpp:394-404, :406-414)."""
+    f = o.build_scenario(o.StructuredFilter, o.Config.kinect(), 6, np.float64)
+    assert [ft.real_index for ft in f.features] == [1, 2, 3, 4, 5, 6] and f.patchnumbre == 7
+    for i in (1, 3):
+        p = f.features[i].position_in_state
+        f.Sigma[p + 5, p + 5] = 1e-9
+    assert f.convert2xyz_if_linear_all() == 2
+    f.mu[13] = 2.0                                        # map_scale
+    t = o.get_points_features(f)
+    assert t.shape == (7, 12) and not t[0].any() and not t[1].any() and not t[3].any()
+    p = f.features[1].position_in_state
+    assert np.array_equal(t[2, :3], f.mu[p:p+3] * 2.0) and np.array_equal(t[2, 3:], f.Sigma[p:p+3, p:p+3].reshape(-1))
+    f.features[1].n_find = 6
+    xyz, cov = f.mu[p:p+3].copy(), f.Sigma[p:p+3, p:p+3].copy()
+    f.remove_feature(1)
+    f.remove_feature(2)                                   # the other XYZ patch (real_index 4), n_find = 1: not kept
+    assert [d[0] for d in f.deleted_patches] == [2]
+    f.mu[0:3] += 1.0                                      # whatever happens to the filter afterwards
+    t = o.get_points_features(f)
+    assert t.shape == (7, 12) and np.array_equal(t[2, :3], xyz * 2.0) and np.array_equal(t[2, 3:], cov.reshape(-1))
+    assert not t[4].any()
+    f.remove_feature(len(f.features) - 1)                 # last live patch gone: the table ends at real_index 5
+    assert o.get_points_features(f).shape == (6, 12)
+    assert f.add_feature(100.0, 100.0) == 1 and f.features[-1].real_index == 7

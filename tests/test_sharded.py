@@ -376,88 +376,132 @@ def test_hip_shard_full_size_matches_plain_path(world, n_feat):
     assert seen.all()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 5])
+def test_hip_shard_n1000_ranks_match_fp64_oracle(world):
+    """BASELINE configs[3] against the ORACLE, not only against the plain HIP path (VERDICT r2 next #1b): N = M = 1000,
+    fp32, two frames of the bench stream on 2 and on 5 ranks sharing the GPU (the box allows six GPU processes at a
+    time and this pytest process is one of them, so 8 ranks cannot run here) -- every rank's camera rows + own rows of
+    Sigma and its replicated mu against the fp64 structured oracle, at the ceilings of the single-GPU fp32 tests."""
+    from helpers import n1000_oracle
+    n_feat, frames = 1000, 2
+    px0, z, states = n1000_oracle(frames)
+    mu_ref, S_ref = states[frames]
+    z_np = np.ascontiguousarray(z.reshape(frames, -1), np.float32)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gpu_static_worker, args=(world, free_port(), n_feat, frames, z_np, px0, out), nprocs=world, join=True)
+    seen = np.zeros(14 + 6 * n_feat, bool)
+    for rank in range(world):
+        mu, rows, S_rows = out[rank]
+        assert np.all(np.isfinite(mu)) and np.all(np.isfinite(S_rows))
+        # the ceilings of test_n1000_default_pipeline_matches_fp64_oracle for the second frame
+        assert bound("rank mu vs fp64 oracle", relf(mu, mu_ref), 1e-5)
+        assert bound("rank Sigma rows vs fp64 oracle", relf(S_rows, S_ref[rows]), 1e-4)
+        own = rows[14:]
+        assert bound("rank own Sigma rows, feature columns, vs fp64 oracle", relf(S_rows[14:, 14:], S_ref[own][:, 14:]), 1e-4)
+        seen[rows] = True
+    assert seen.all()
+
+
+# BASELINE configs[4]: N = 4000, fp32, dynamic add / delete-feature covariance resize every 50 frames
+N4000_FRAMES = 101            # resize after frames 49 and 99 (counting from 0), one more frame on the resized map
+
+
+def n4000_cadence_run(pkg, flt, frames=N4000_FRAMES, every=50, n_feat=4000, progress=None):
+    """The same calls for the plain and for the sharded filter: `frames` frames of the bench stream with every visible
+    surviving feature measured; after every `every`-th frame 1 % of the features are removed (uniform indices, handed
+    over in one call: the library removes in descending order as vR.cpp:1296 does) and as many are added at the end
+    (vR.cpp:1300-1315), which are never measured (no stream behind them).  Returns mu, a sample of row indices and
+    the invariants."""
+    from ekf_monoslam_amd import synthetic
+    cfg = pkg.kinect_config()
+    px0, z = synthetic.measurement_stream(cfg, n_feat, frames, sigma_px=0.5)
+    for (u, v) in px0:
+        assert flt.addFeature((u, v)) == 1
+    yield "built"
+    rng = np.random.default_rng(1236)
+    sid = np.arange(n_feat)                       # stream index behind every current feature, -1: none
+    for k in range(frames):
+        flt.predict()
+        h, vis, rem, _ = flt.predictions()
+        sel = np.nonzero(vis.astype(bool) & (sid >= 0))[0].astype(np.int32)
+        flt.update(z[k][sid[sel]].reshape(-1), sel)
+        if (k + 1) % every == 0:
+            N = flt.numOfFeatures()
+            drop = sorted(rng.choice(N, size=N // 100, replace=False).tolist())
+            flt.removeFeatures(drop)
+            sid = np.delete(sid, drop)
+            for _ in range(len(drop)):
+                assert flt.addFeature((float(rng.uniform(20, 300)), float(rng.uniform(20, 220)))) == 1
+            sid = np.concatenate([sid, -np.ones(len(drop), np.int64)])
+            assert flt.numOfFeatures() == N == len(sid)
+        if progress and k % 10 == 9:
+            progress(k)
+    flt.synchronize()
+    yield "done"
+
+
 def _gpu_n4000_worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from __graft_entry__ import load_package
     pkg = load_package()
-    from ekf_monoslam_amd import sharded, synthetic
+    from ekf_monoslam_amd import sharded
     N = 4000
-    cfg = pkg.kinect_config()
-    px0, z = synthetic.measurement_stream(cfg, N, 2, sigma_px=0.5)
-    flt = pkg.VSlamFilter(cfg, capacity_features=N + 64, dtype=np.float32)
+    flt = pkg.VSlamFilter(pkg.kinect_config(), capacity_features=N + 64, dtype=np.float32)
     flt.setDt(1.0 / 30.0)
-    for (u, v) in px0:
-        assert flt.addFeature((u, v)) == 1
+    run = n4000_cadence_run(pkg, flt, progress=(lambda k: print(f"[n4000 x{world}] frame {k + 1}", flush=True)) if rank == 0 else None)
+    next(run)
     sharded.configure(flt, rank, world)
-    rng = np.random.default_rng(1236)
-    drop = sorted(rng.choice(N, size=40, replace=False).tolist())       # 1 % out, the same number in (SURVEY 8d, configs[4])
-    add = [(float(rng.uniform(20, 300)), float(rng.uniform(20, 220))) for _ in range(40)]
-    idx = np.arange(N, dtype=np.int32)
-    flt.predict()
-    flt.update(z[0].reshape(-1), idx)
-    flt.removeFeatures(drop)
-    for (u, v) in add:
-        assert flt.addFeature((u, v)) == 1
-    keep = np.setdiff1d(np.arange(N), drop)
-    flt.predict()
-    h, vis, rem, _ = flt.predictions()
-    sel = np.nonzero(vis[:len(keep)])[0].astype(np.int32)                # the surviving features of the stream that are visible
-    flt.update(z[1][keep][sel].reshape(-1), sel)
-    flt.synchronize()
+    next(run)
     info = sharded.shard_info(flt)
     pad, asym, big = flt.checkInvariants()
     rows = np.r_[0:14, info.row_begin:min(info.row_begin + 200, info.row_end), max(info.row_begin, info.row_end - 200):info.row_end]
     blocks = [flt.getSigmaBlock(int(r), 0, 1, flt.stateDim()) for r in rows[::7]]
-    out[rank] = (flt.getFullState(), rows[::7], np.concatenate(blocks), (info.f_begin, info.f_end), pad, flt.numOfFeatures())
+    out[rank] = (flt.getFullState(), rows[::7], np.concatenate(blocks), (info.f_begin, info.f_end), pad, flt.numOfFeatures(),
+                 info.rebalances)
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-def test_hip_shard_n4000_resize_two_ranks_match_plain_path():
-    """BASELINE configs[4] at FULL size (N = 4000, n = 24 014, fp32, 63 block steps) under sharding: two ranks sharing the GPU
-    (collectives through gloo), one frame, 1 % of the features removed and as many added (descending removal order,
-    additions at the end, vR.cpp:1296-1315), a second frame on a measured subset -- every rank's rows against the plain
-    single-GPU path on the same calls."""
+def test_hip_shard_n4000_resize_cadence_two_ranks_match_plain_path():
+    """BASELINE configs[4] at FULL size and at its CADENCE (VERDICT r2 next #1d): N = 4000, n = 24 014, fp32, 63 block
+    steps, 101 frames with 1 % of the features removed and as many added after every 50th frame, on two ranks sharing
+    the GPU (collectives through gloo) -- every rank's rows against the plain single-GPU path on the same calls, the
+    zero padding and the symmetry of the plain path's covariance checked on the device after the last frame.
+    (The fp64 oracle cannot follow at this size: one dense update is 9 TFLOP and Sigma 4.6 GB.)"""
     from __graft_entry__ import load_package
     pkg = load_package()
-    from ekf_monoslam_amd import synthetic
     N = 4000
-    cfg = pkg.kinect_config()
-    px0, z = synthetic.measurement_stream(cfg, N, 2, sigma_px=0.5)
-    flt = pkg.VSlamFilter(cfg, capacity_features=N + 64, dtype=np.float32)
+    flt = pkg.VSlamFilter(pkg.kinect_config(), capacity_features=N + 64, dtype=np.float32)
     flt.setDt(1.0 / 30.0)
-    for (u, v) in px0:
-        assert flt.addFeature((u, v)) == 1
-    rng = np.random.default_rng(1236)
-    drop = sorted(rng.choice(N, size=40, replace=False).tolist())
-    add = [(float(rng.uniform(20, 300)), float(rng.uniform(20, 220))) for _ in range(40)]
-    idx = np.arange(N, dtype=np.int32)
-    flt.predict()
-    flt.update(z[0].reshape(-1), idx)
-    flt.removeFeatures(drop)
-    for (u, v) in add:
-        assert flt.addFeature((u, v)) == 1
-    keep = np.setdiff1d(np.arange(N), drop)
-    flt.predict()
-    h, vis, rem, _ = flt.predictions()
-    sel = np.nonzero(vis[:len(keep)])[0].astype(np.int32)
-    flt.update(z[1][keep][sel].reshape(-1), sel)
-    flt.synchronize()
+    # the same column chunks as the two-rank step (4 equal chunks; the plain default is 3 / 8 / 16 sixteenths): every
+    # tile product then sums the same terms in the same order on both paths, and the comparison below is EXACT.  (With
+    # different chunk plans the two fp32 runs drift apart by 1e-5 .. 1e-3 over 100 frames -- rounding differences of
+    # 1e-7 in V amplified by the filter, tools/shard_cadence_probe.py -- which would say nothing about the sharding.)
+    flt.set_option(3, 4)
+    for _ in n4000_cadence_run(pkg, flt, progress=lambda k: print(f"[n4000 plain] frame {k + 1}", flush=True)):
+        pass
     mu_p = flt.getFullState()
     n = flt.stateDim()
+    pad, asym, big = flt.checkInvariants()
+    assert pad == 0.0 and asym == 0.0 and np.isfinite(big)
+    assert np.all(np.isfinite(mu_p)) and abs(np.linalg.norm(mu_p[3:7]) - 1.0) < 1e-5
+    d = np.diag(flt.getSigmaBlock(0, 0, 2000, 2000))
+    assert np.all(d > 0)
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_gpu_n4000_worker, args=(2, free_port(), out), nprocs=2, join=True)
     ranges = []
     for rank in range(2):
-        mu, rows, S_rows, frange, pad, nfeat = out[rank]
+        mu, rows, S_rows, frange, pad, nfeat, rebal = out[rank]
         assert nfeat == N and mu.shape == (n,) and np.all(np.isfinite(mu)) and pad == 0.0
-        assert bound("rank mu vs plain path", relf(mu, mu_p), 2e-5)
         ref_rows = np.concatenate([flt.getSigmaBlock(int(r), 0, 1, n) for r in rows])
-        assert bound("rank Sigma rows vs plain path", relf(S_rows, ref_rows), 5e-4)
+        assert np.array_equal(mu, mu_p), relf(mu, mu_p)                # bit-identical after 101 frames and two resizes
+        assert np.array_equal(S_rows, ref_rows), relf(S_rows, ref_rows)
         ranges.append(frange)
     assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == N
 
