@@ -208,16 +208,6 @@ struct Filter : FilterBase {
   unsigned char* d_found = nullptr;
   float* d_score = nullptr;
   int* d_keep = nullptr;
-  // Fused chunk launches (k_gemm_tasks): solve + W update + downdate of a column chunk as ONE persistent launch with
-  // in-launch row-block dependencies.  EKF_FUSED=0: the launch-per-product path (A/B runs, tools/knob_ab.py).
-  int opt_fused = 0;
-  int opt_task_order = 1;                               // EKF_TASK_ORDER (A/B)
-  int opt_tail_overlap = 0;                             // EKF_TAIL_OVERLAP (A/B)
-  float* d_ZT = nullptr;                                // transposed chunk inverses L_gg^-1 (row-major lower), ldy x ldy, lazily
-  int* d_tasks = nullptr;
-  size_t tasks_cap = 0;
-  std::vector<int> tasks_key;                           // (npad_live, m_pad, slots, chunk ends) the cached lists were built for
-  int task_off[8] = {}, task_cnt[8] = {};
   int opt_panel_direct = 1;                             // EKF_PANEL_DIRECT=0: panel through the general tile GEMM
   int opt_fuse_wu = 1;                                  // EKF_FUSE_WU: 0 never, 1 every overlapped chunk but the one before the last, 2 every overlapped chunk
   int env_chunks[8] = {}, env_nchunks = 0;               // EKF_CHUNKS="5,10,14,16": tuning knob (block steps)
@@ -252,7 +242,7 @@ struct Filter : FilterBase {
                     d_flags, d_cflag, d_Jy, d_Yxyz, d_map_src, d_map_conv, d_Y, d_W, d_V, d_Dinv, d_z, d_midx,
                     d_status, d_tmp, d_K, d_tilemap, d_counters, d_ibuf, d_rmask, d_pts,
                     d_frame, d_patch[0], d_patch[1], d_mpatch[0], d_mpatch[1], d_hb, d_zm, d_found, d_score, d_keep,
-                    d_Vs[0], d_Vs[1], d_Vs[2], d_stage_send, d_stage_recv, d_ZT, d_tasks, d_archive, d_arch_idx};
+                    d_Vs[0], d_Vs[1], d_Vs[2], d_stage_send, d_stage_recv, d_archive, d_arch_idx};
     for (void* p : ptrs) if (p) hipFree(p);
     if (own_stream && stream) hipStreamDestroy(stream);
     if (stream_b) hipStreamDestroy(stream_b);
@@ -404,9 +394,6 @@ struct Filter : FilterBase {
         stream_c = nullptr;
         HIPCHK(hipStreamCreateWithFlags(&stream_c, hipStreamNonBlocking));
       }
-      if (const char* e = getenv("EKF_FUSED")) opt_fused = atoi(e);
-      if (const char* e = getenv("EKF_TASK_ORDER")) opt_task_order = atoi(e);
-      if (const char* e = getenv("EKF_TAIL_OVERLAP")) opt_tail_overlap = atoi(e);
       if (const char* e = getenv("EKF_FUSE_WU")) opt_fuse_wu = atoi(e);
       if (const char* e = getenv("EKF_PANEL_DIRECT")) opt_panel_direct = atoi(e);
       if (const char* e = getenv("EKF_SPLIT_TAIL")) opt_split_tail = atoi(e);
@@ -460,9 +447,8 @@ struct Filter : FilterBase {
     int st[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(st, d_status, sizeof(st), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
-    if (st[0] || st[1] || st[3]) {
+    if (st[0] || st[1]) {
       HIPCHK(hipMemsetAsync(d_status, 0, 4 * sizeof(int), stream));
-      if (st[3]) FAIL(EKF_ERR_DEVICE, "fused chunk launch: a tile waited ~0.3 s for the rows of V it reads and gave up");
       if (st[1])
         FAIL(EKF_ERR_ARG, "ekf_update_device: a device-resident index is outside [0, N) or the list is not strictly "
                           "ascending (indices were clamped; the state is not meaningful)");
@@ -904,7 +890,7 @@ struct Filter : FilterBase {
     if (!st) st = stream;
     const bool mf = kIsF32 && opt_mfma;
     dim3 grid(cols / (mf ? TN : 64), rows / (mf ? TM : 64));
-    if (tile_list && counter_next + 8 <= kQueueHeads) {
+    if (tile_list && counter_next + 8 <= kQueueCounters) {
       g.tile_map = tile_list;
       g.ntiles = ntiles;
       g.counter = d_counters + counter_next;
@@ -1090,77 +1076,6 @@ struct Filter : FilterBase {
     return EKF_OK;
   }
 
-  // Task lists of the fused chunk launches (k_gemm_tasks) for (npad_live, m_pad, chunk plan): per chunk, in an order in
-  // which every task's dependencies come earlier -- row block by row block, the solve tiles of row block I (heaviest
-  // first), then, L row blocks behind them, the W-update and downdate tiles that read row block I - L (L x the solve
-  // tiles of a row block ~ the workgroups of the launch: by the time a workgroup draws a dependent tile its rows have
-  // normally been solved).  The last 1.5 tiles per CU of the LAST chunk's list go out as 64 x 128 halves.
-  int ensure_tasks(int npad_live, int m_pad, int nchunks, const int* cend) {
-    const int nb = 128;
-    std::vector<int> key = {npad_live, m_pad, num_cus, reserved_cus, opt_split_tail, opt_task_order, nchunks};
-    for (int g = 0; g < nchunks; ++g) key.push_back(cend[g]);
-    if (key == tasks_key) return EKF_OK;
-    const int ntr = npad_live / nb + 1, nts = npad_live / nb, ntc = m_pad / nb;
-    std::vector<int> tasks;
-    auto push = [&](int type, int bi, int bj, int half = 0) {
-      tasks.push_back(bi | (half ? kTaskHalf : 0) | (type << kTaskTypeShift));
-      tasks.push_back(bj);
-    };
-    for (int g = 0; g < nchunks; ++g) {
-      const int s0 = g ? cend[g - 1] : 0, s1 = cend[g], wt = s1 - s0, ncw = ntc - s1;
-      const bool last = (g + 1 == nchunks);
-      const int slots = 2 * ((last || !stream_b) ? num_cus : num_cus - reserved_cus);
-      const int L = std::max(1, (slots + wt - 1) / wt);
-      task_off[g] = (int)tasks.size() / 2;
-      std::vector<std::pair<int, int>> dd;          // downdate tiles in list order (for the half tiles of the last chunk)
-      const size_t first = tasks.size();
-      const int order = opt_task_order;               // 0: W-update and downdate tiles of a row block together; 1: every W update first
-      for (int I = 0; I < ntr + L; ++I) {
-        if (I < ntr)
-          for (int j = wt - 1; j >= 0; --j) push(TASK_SOLVE, I, j);
-        const int r = I - L;
-        if (r < 0 || r >= ntr) continue;
-        for (int c = 0; c < ncw; ++c) push(TASK_WUPDATE, r, c);
-        if (order == 0 && r < nts)
-          for (int J = 0; J <= r; ++J) push(TASK_DOWNDATE, r, J);
-      }
-      if (order != 0)
-        for (int r = 0; r < nts; ++r)
-          for (int J = 0; J <= r; ++J) push(TASK_DOWNDATE, r, J);
-      if (last) {
-        // half tiles: rewrite the tail of this chunk's list (the downdate tiles of the last rows)
-        int ndd = 0;
-        for (size_t t = first; t < tasks.size(); t += 2) ndd += ((tasks[t] >> kTaskTypeShift) == TASK_DOWNDATE);
-        int ns_ = (opt_split_tail < 0) ? std::min(3 * num_cus / 2, ndd / 3) : std::min(opt_split_tail, ndd);
-        std::vector<int> tail;
-        while (ns_ > 0 && tasks.size() > first && (tasks[tasks.size() - 2] >> kTaskTypeShift) == TASK_DOWNDATE) {
-          const int bj = tasks.back(); tasks.pop_back();
-          const int bi = tasks.back() & 0xffff; tasks.pop_back();
-          tail.push_back(bi); tail.push_back(bj);
-          --ns_;
-        }
-        for (size_t t = tail.size(); t >= 2; t -= 2)
-          for (int h = 0; h < 2; ++h) push(TASK_DOWNDATE, 2 * tail[t - 2] + h, tail[t - 1], 1);
-      }
-      task_cnt[g] = (int)tasks.size() / 2 - task_off[g];
-    }
-    HIPCHK(hipStreamSynchronize(stream));
-    if (stream_b) HIPCHK(hipStreamSynchronize(stream_b));
-    if (tasks.size() > tasks_cap) {
-      if (d_tasks) HIPCHK(hipFree(d_tasks));
-      d_tasks = nullptr;
-      HIPCHK(hipMalloc(&d_tasks, tasks.size() * sizeof(int)));
-      tasks_cap = tasks.size();
-    }
-    HIPCHK(hipMemcpy(d_tasks, tasks.data(), tasks.size() * sizeof(int), hipMemcpyHostToDevice));
-    if (!d_ZT) {
-      HIPCHK(hipMalloc(&d_ZT, (size_t)ldy * ldy * sizeof(T)));
-      HIPCHK(hipMemset(d_ZT, 0, (size_t)ldy * ldy * sizeof(T)));
-    }
-    tasks_key = key;
-    return EKF_OK;
-  }
-
   // Block steps [step0, step1) of the serial chain of chunk [c0, c1) on stream sc_: diagonal factor, panel (rows
   // below the block + the chunk's identity-strip rows), trailing update (strip tiles stop at c1).
   void chain_steps(int step0, int step1, int c0, int c1, int m, int m_pad, hipStream_t sc_) {
@@ -1266,91 +1181,9 @@ struct Filter : FilterBase {
     rc = ensure_tilemap(npad_live / tile, ntr, ntc);
     if (rc) return rc;
 
-    bool use_fused = false;
-    if constexpr (kIsF32)
-      use_fused = opt_fused && opt_mfma && tile == 128 && tri_count >= num_cus && !opt_split_bf16 &&
-                  ntr <= kTaskRowBlocks && nchunks <= 8 && counter_next + 8 * nchunks <= kQueueHeads;
-    if (use_fused) {
-      if constexpr (kIsF32) {
-        rc = ensure_tasks(npad_live, m_pad, nchunks, cend);
-        if (rc) return rc;
-        int step_ = 0, prev_grid = 0;
-        bool side_busy = false;
-        for (int gi = 0; gi < nchunks; ++gi) {
-          const int c0 = step_ * nb, c1 = cend[gi] * nb, width = c1 - c0;
-          chain_steps(step_, cend[gi], c0, c1, m, m_pad, stream);
-          step_ = cend[gi];
-          const bool overlap = (stream_b != nullptr) && (gi + 1 < nchunks);
-          hipStream_t ss = overlap ? stream_b : stream;
-          // cross-launch overlap (EKF_TAIL_OVERLAP): the last chunk's launch goes out when the chain is done and takes its
-          // dependencies on the previous chunk's launch (still running on the second stream) from device counters
-          const bool before_last = overlap && gi + 2 == nchunks && opt_tail_overlap;
-          const bool tail_overlap = !overlap && side_busy && opt_tail_overlap && gi > 0;
-          if (overlap) {
-            HIPCHK(hipEventRecord(ev_chain[gi], stream));
-            HIPCHK(hipStreamWaitEvent(stream_b, ev_chain[gi], 0));
-            side_busy = true;
-          }
-          {
-            Scope sc(this, KID_SOLVE, ss);              // L_gg^-1 row-major: the NT operand of the solve tiles (needs the chain only)
-            k_transpose_lower<<<dim3(width / 32, width / 32), 256, 0, ss>>>(Zs + c0, ldy, d_ZT + (size_t)c0 * ldy, ldy, width);
-          }
-          if (before_last) HIPCHK(hipEventRecord(ev_wu, stream_b));   // the second stream has reached this chunk's launch
-          if (!overlap && side_busy) {
-            if (tail_overlap) {
-              // only the START of the previous launch is awaited (its workgroups are resident long before this stream has
-              // seen the event): the spinning tiles of this launch can then never keep it off the chip
-              HIPCHK(hipStreamWaitEvent(stream, ev_wu, 0));
-            } else {                                    // every earlier W update and downdate first
-              HIPCHK(hipEventRecord(ev_b, stream_b));
-              HIPCHK(hipStreamWaitEvent(stream, ev_b, 0));
-              side_busy = false;
-            }
-          }
-          Scope sc(this, KID_DOWNDATE, ss);             // the fused launch: solve, W update, downdate of this chunk
-          if (sc.on) {
-            const double w = std::min(c1, m) - std::min(c0, m);
-            prof_work[KID_DOWNDATE] += double(n) * n * w + 2.0 * (n + 1) * std::max(0, m - c1) * w + double(n + 1) * w * w;
-          }
-          TaskArgs a{};
-          a.p[TASK_SOLVE] = TaskProduct{d_W + c0, d_ZT + (size_t)c0 * ldy, d_V + c0, ldy, ldy, ldy, width, 1.f, 0.f, 1, 0};
-          a.p[TASK_WUPDATE] = TaskProduct{d_V + c0, Y + (size_t)c1 * ldy + c0, d_W + c1, ldy, ldy, ldy, width, -1.f, 1.f, 0, 0};
-          a.p[TASK_DOWNDATE] = TaskProduct{d_V + c0, d_V + c0, S(), ldy, ldy, ld, width, -1.f, 1.f, 0, 1};
-          a.tasks = d_tasks + 2 * (size_t)task_off[gi];
-          a.ntasks = task_cnt[gi];
-          a.head = d_counters + counter_next;
-          counter_next += 8;
-          a.vdone = d_counters + kQueueHeads + gi * kTaskRowBlocks;
-          a.need = width / nb;
-          a.status = d_status;
-          a.stagger = 1;
-          const int wgs = 2 * (overlap ? num_cus - reserved_cus : num_cus);
-          const int grid = std::min(a.ntasks, wgs);
-          if (before_last) {
-            a.wdone = d_counters + kQueueHeads + (8 + gi) * kTaskRowBlocks;
-            a.exit_count = d_counters + kTaskExit + 8 * gi;
-            prev_grid = grid;
-          }
-          if (tail_overlap) {
-            a.wprev = d_counters + kQueueHeads + (8 + gi - 1) * kTaskRowBlocks;
-            a.wprev_need = (m_pad - c0) / nb;                        // W-update tiles per row block of the previous launch
-            a.prev_exit = d_counters + kTaskExit + 8 * (gi - 1);
-            a.prev_exit_need = prev_grid;
-          }
-          k_gemm_tasks<<<grid, 256, 0, ss>>>(a);
-        }
-        if (side_busy) {                                // (the tail has waited for the second stream on the device; the
-          HIPCHK(hipEventRecord(ev_b, stream_b));       // stream order is restored here, where it costs nothing)
-          HIPCHK(hipStreamWaitEvent(stream, ev_b, 0));
-          side_busy = false;
-        }
-        Scope sc(this, KID_STATE_UPDATE);               // every column of V and y = L^-1 nu exist: mu += V y (+ quaternion)
-        k_state_update<T><<<(n + 7) / 8, 512, 0, stream>>>(mu(), d_V, ldy, n, d_V + (size_t)npad_live * ldy, m_pad, d_scr + SCR_QN);
-      }
-    }
     int step = 0;
     bool b_inflight = false;
-    for (int gi = 0; gi < (use_fused ? 0 : nchunks); ++gi) {
+    for (int gi = 0; gi < nchunks; ++gi) {
       const int c0 = step * nb, c1 = cend[gi] * nb;
       // chunk 0 has the chip to itself; later chunks run beside the tile GEMMs of stream_b, on the reserved CUs
       hipStream_t sc_ = stream;
@@ -1391,7 +1224,7 @@ struct Filter : FilterBase {
       bool fuse = false;
       if constexpr (kIsF32)
         fuse = opt_fuse_wu && (opt_fuse_wu > 1 || gi + 2 < nchunks) && opt_mfma && overlap && c1 < m_pad &&
-               !opt_split_bf16 && tile == 128 && tri_count >= num_cus && counter_next + 8 <= kQueueHeads;
+               !opt_split_bf16 && tile == 128 && tri_count >= num_cus && counter_next + 8 <= kQueueCounters;
       if (c1 < m_pad && !fuse) {
         Scope sc(this, KID_WUPDATE, ss);
         const int slots = 2 * (overlap ? num_cus - reserved_cus : num_cus);
@@ -1476,7 +1309,7 @@ struct Filter : FilterBase {
     for (int g = 0; g < nchunks; ++g) last_cend[g] = cend[g];
     const T* V = d_V;
     const T* yv = d_V + (size_t)npad_live * ldy;
-    if (nchunks == 1 && !use_fused) {
+    if (nchunks == 1) {
       Scope sc(this, KID_STATE_UPDATE);             // mu += V y, then the quaternion normalisation (same launch)
       k_state_update<T><<<(n + 7) / 8, 512, 0, stream>>>(mu(), V, ldy, n, yv, m_pad, d_scr + SCR_QN);
     }

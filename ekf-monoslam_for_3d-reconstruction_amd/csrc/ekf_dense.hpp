@@ -18,10 +18,7 @@ namespace ekf {
 // ---------------------------------------------------------------------------------------
 // nu = z - h for the measured list (+ plane rows: 0 - mu[{1,4,6}], vR.cpp:1257-1260).
 // ---------------------------------------------------------------------------------------
-constexpr int kQueueHeads = 256;                 // work-queue heads of the queued launches of one update (8 ints apart)
-constexpr int kTaskRowBlocks = 256;              // row blocks of [W; nu^T] a fused chunk launch can track (n_pad <= 32 640)
-constexpr int kTaskExit = kQueueHeads + 16 * kTaskRowBlocks;        // exit counters of the fused launches, 8 ints apart
-constexpr int kQueueCounters = kTaskExit + 64;   // heads | vdone[chunk][row block] | wdone[chunk][row block] | exit[chunk]; zeroed per update
+constexpr int kQueueCounters = 256;              // work-queue heads of the queued launches of one update (8 ints apart)
 
 // A measured list read from DEVICE memory (ekf_update_device) cannot be checked on the host: an entry outside
 // [0, nfeat) or a list that is not strictly ascending raises status[1] (the next synchronising call returns
@@ -362,208 +359,6 @@ __global__ void __launch_bounds__(256) k_gemm_valu(GemmArgs g) {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// One TMb x TN output tile of C = beta C + alpha A op(B) on the f32 matrix pipe, K a multiple of 32.
-//   A  rows bi * TMb .. of A (row stride lda, K-contiguous)
-//   B  NT (BT = false): rows bj * TN .. of B (row stride ldb, K-contiguous);  NN (BT = true): columns bj * TN .. (K rows)
-//   C  tile (bi, bj) of C (row stride ldc);  mirror: also store the transposed tile (bj, bi) (symmetric update)
-//   (base pointers + tile indices, not tile origins: with the origins formed by the caller hipcc needs ~50 more
-//   registers for the same loop -- 256 and spills against 205 on the 128 x 128 shape)
-//   lds: 2 stages x 8 x (TMb + TN) 16-byte slots, free when the call starts (the call begins with a barrier)
-// 256 lanes = 4 waves as 2 x 2, each wave (TMb/2) x (TN/2) = MI x NJ accumulators of 32 x 32.
-// SGB: place the ds_writes of the next stage between the MFMAs of the first group (sched_group_barrier): helps every NT
-// shape with 128 columns, hurts the 64 x 64 chain tiles and the NN tiles, so the callers choose.
-template <bool BT, int TMb, int TN, bool SGB>
-__device__ __forceinline__ void mfma_tile(const float* A, int lda, const float* B, int ldb,
-                                          float* C, int ldc, bool mirror, int K, float alpha,
-                                          float beta, f32x4* lds, int tid, int bi, int bj) {
-  constexpr int NT = 256, WC = 2, BK = 32, NQ = BK / 4, NJ = TN / (32 * WC), PB = TN * 8 / NT;
-  constexpr int MI = TMb / 64, PA = TMb * 8 / NT;
-  constexpr int STAGE = NQ * (TMb + TN);
-  static_assert((TMb == 64 || TMb == 128) && (TN == 64 || TN == 128), "tile shape");
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wr = wave / WC, wc = wave % WC;
-  // A staging: TMb*8 float4 per tile, PA per lane; 8 consecutive lanes cover 128 B of a row
-  const float* Ag[PA];
-  const float* Bg[4];
-  int aslot[PA], bslot[4];
-#pragma unroll
-  for (int p = 0; p < PA; ++p) {
-    const int idx = tid + NT * p;
-    const int row = idx >> 3, q = idx & 7;
-    Ag[p] = A + (size_t)(bi * TMb + row) * lda + q * 4;
-    aslot[p] = q * TMb + (row ^ q);
-  }
-  // NN mode: lane owns k-quad qk and column quad cq: rows 4qk+p (p < 4), 4 columns; TN = 64 uses lanes < 128
-  const int qk = tid / (TN / 4), cq = tid % (TN / 4);
-  const bool bt_active = !BT || qk < NQ;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    if (!BT) {
-      const int idx = tid + NT * p;
-      const int row = idx >> 3, q = idx & 7;
-      Bg[p] = (p < PB) ? B + (size_t)(bj * TN + row) * ldb + q * 4 : B;
-      bslot[p] = q * TN + (row ^ q);
-    } else {
-      Bg[p] = B + (size_t)(4 * (bt_active ? qk : 0) + p) * ldb + bj * TN + 4 * cq;
-      bslot[p] = qk * TN + ((4 * cq + p) ^ qk);
-    }
-  }
-  const int h = lane >> 5, l31 = lane & 31;
-  // The accumulators start at zero and C enters once, in the epilogue (C' = beta C + alpha acc, one rounding at
-  // the magnitude of C).  Starting them at (beta / alpha) C instead -- the C tile read up front, the epilogue a pure
-  // store -- rounds every one of the K partial sums at the magnitude of C: the products below half an ulp of C are
-  // dropped one by one, and the covariance downdate then loses positivity after ~1700 all-measured frames at N = 200
-  // where this form holds it (tools/drift_hybrid.py, profiles/r2_drift_hybrid.txt).
-  f32x16 acc[MI][NJ];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  constexpr int PBL = BT ? 4 : PB;             // B float4 loads per lane
-  f32x4 ra[PA], rb[4];
-  auto load_tile = [&](int k0) {
-#pragma unroll
-    for (int p = 0; p < PA; ++p) ra[p] = *reinterpret_cast<const f32x4*>(Ag[p] + k0);
-#pragma unroll
-    for (int p = 0; p < PBL; ++p)
-      rb[p] = BT ? *reinterpret_cast<const f32x4*>(Bg[p] + (size_t)k0 * ldb) : *reinterpret_cast<const f32x4*>(Bg[p] + k0);
-  };
-  auto store_tile = [&](int stage) {
-    f32x4* As = lds + stage * STAGE;
-    f32x4* Bs = As + NQ * TMb;
-#pragma unroll
-    for (int p = 0; p < PA; ++p) As[aslot[p]] = ra[p];
-    if (!BT) {
-#pragma unroll
-      for (int p = 0; p < PB; ++p) Bs[bslot[p]] = rb[p];
-    } else if (bt_active) {
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {          // column 4cq+p gets (k0..k3) of that column
-        f32x4 t = {rb[0][p], rb[1][p], rb[2][p], rb[3][p]};
-        Bs[bslot[p]] = t;
-      }
-    }
-  };
-  // software pipeline: tile k computes from stage k&1 while tile k+1 is written to the other stage and
-  // tile k+2 is in flight from global memory; one barrier per K step.  The A / B fragments are double
-  // buffered too: the ds_reads of MFMA group g+1 go out before the 16 MFMAs of group g, and the first
-  // group of the NEXT stage is fetched right after the barrier, under the last group of this one, so the
-  // matrix pipe never waits for an LDS round trip.
-  constexpr int NG = BK / 8;                   // MFMA groups per K step (each: one b128 per fragment, 4 k-pairs)
-  static_assert(NG % 2 == 0, "fragment ping-pong assumes an even number of groups");
-  f32x4 fa[2][MI], fb[2][NJ];
-  auto read_frag = [&](int stage_, int s, int buf) {
-    const f32x4* As = lds + stage_ * STAGE;
-    const f32x4* Bs = As + NQ * TMb;
-    const int q = 2 * s + h;
-#pragma unroll
-    for (int t = 0; t < MI; ++t) {
-      const int ar = wr * (TMb / 2) + t * 32 + l31;
-      fa[buf][t] = As[q * TMb + (ar ^ q)];
-    }
-#pragma unroll
-    for (int t = 0; t < NJ; ++t) {
-      const int br = wc * (TN / WC) + t * 32 + l31;
-      fb[buf][t] = Bs[q * TN + (br ^ q)];
-    }
-  };
-  auto mfma_group = [&](int buf) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][i][e], fb[buf][j][e], acc[i][j], 0, 0, 0);
-  };
-  __syncthreads();                             // the previous tile of this workgroup is done with the LDS
-  load_tile(0);
-  store_tile(0);
-  if (BK < K) load_tile(BK);
-  __syncthreads();
-  read_frag(0, 0, 0);
-  int stage = 0;
-  // one K step; `more` (another step follows: stage the tile in registers) and `more2` (one more after that: fetch it)
-  // are compile-time, so the steady-state step is ONE basic block and the scheduler may place the ds_writes and the
-  // global loads between the MFMAs instead of behind a branch after them
-  auto kstep = [&](auto more_t, auto more2_t, int k0) {
-    constexpr bool more = decltype(more_t)::value, more2 = decltype(more2_t)::value;
-#pragma unroll
-    for (int s = 0; s < NG; ++s) {
-      if (s + 1 < NG) {
-        read_frag(stage, s + 1, (s + 1) & 1);
-      } else {
-        __syncthreads();                       // stage^1 is complete, everybody has read this stage
-        if (more) read_frag(stage ^ 1, 0, 0);
-      }
-      mfma_group(s & 1);
-      if (s == 0 && more) {
-        store_tile(stage ^ 1);
-        if (more2) load_tile(k0 + 2 * BK);
-        if constexpr (more && more2 && SGB) {
-          // steady state: one ds_write after every few MFMAs of this group instead of all of them in a row behind it
-          // (the stores wait for their global loads one by one; in a row they leave the matrix pipe with one
-          // instruction in flight).  128 x 128 NT tile: alone on a CU a K = 1024 tile 85.8 -> 79.1 us, the 1128-tile
-          // launch 339 -> 331 us, the N = 1000 step 1.320 -> 1.305 ms
-          constexpr int NWRITE = BT ? 4 : PA + PB, NMFMA = 4 * MI * NJ, R = NMFMA / NWRITE > 0 ? NMFMA / NWRITE : 1;
-#pragma unroll
-          for (int i = 0; i < NWRITE; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, R, 0);    // R MFMAs
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);    // one ds_write
-          }
-          // (also tried: one write per MFMA; the global loads spread the same way after the writes, one per MFMA or
-          // per two: each 2 % slower on the 1128-tile launch.  Shapes: NT tiles with 128 columns -- 128 x 128 and the
-          // 64 x 128 of the W update and of the half tiles -- gain; the 64 x 64 chain tiles and the NN solve tiles lose)
-        }
-        // (left alone, the scheduler sinks these loads to the end of the step, ~600 cycles before the stores that
-        // consume them; pinning them here with sched_barrier(0), a whole step ahead, measured SLOWER: a 2-round
-        // K = 1024 launch 337 against 292 us, the step 1.332 against 1.320 ms)
-      }
-    }
-    stage ^= 1;
-  };
-  {
-    using yes = std::true_type;
-    using no = std::false_type;
-    int k0 = 0;
-    for (; k0 + 2 * BK < K; k0 += BK) kstep(yes{}, yes{}, k0);
-    if (k0 + BK < K) { kstep(yes{}, no{}, k0); k0 += BK; }
-    kstep(no{}, no{}, k0);
-  }
-  // epilogue: acc reg e of lane -> row (e&3) + 8*(e>>2) + 4*h, col l31 of the 32x32 tile
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int rbase = bi * TMb + wr * (TMb / 2) + i * 32;
-      const int c = bj * TN + wc * (TN / WC) + j * 32 + l31;
-      float v[16];
-      if (beta != 0.f) {                       // the 16 C loads of a 32 x 32 block go out together, ahead of their use
-        const float* Cp = C + (size_t)(rbase + 4 * h) * ldc + c;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = beta * Cp[(size_t)((e & 3) + 8 * (e >> 2)) * ldc];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = __builtin_fmaf(alpha, acc[i][j][e], v[e]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = alpha * acc[i][j][e];
-      }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) C[(size_t)(rbase + (e & 3) + 8 * (e >> 2) + 4 * h) * ldc + c] = v[e];
-      if (mirror) {
-        // 4 consecutive regs are 4 consecutive rows -> one 16-byte store into the transposed tile
-        float* Ct = C + (size_t)c * ldc;
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          f32x4 o = {v[4 * gq], v[4 * gq + 1], v[4 * gq + 2], v[4 * gq + 3]};
-          *reinterpret_cast<f32x4*>(Ct + rbase + 8 * gq + 4 * h) = o;
-        }
-      }
-    }
-}
-
 template <int ROLE, bool BT, int TM = 128, int TN = 128>
 // Register budget: two 128 x 128 workgroups per CU (two waves per SIMD each); the 64 x 64 chain tiles (ROLE_TRAILING)
 // are held to 80 registers so that one of them fits on a CU BESIDE two downdate workgroups (2 x 216 + 80 <= 512, LDS
@@ -804,154 +599,6 @@ __global__ void __launch_bounds__(256, (ROLE == ROLE_TRAILING && TM == 64 && TN 
     tile_body(std::integral_constant<int, TM>{});
   }
   }  // tile loop
-}
-
-// ---------------------------------------------------------------------------------------
-// Fused chunk launch (f32, 128-column NT tiles): the triangular solve V_g = [W_g; nu_g^T] Z_gg, the right-looking update
-// W[:, c1:] -= V_g L[c1:, g]^T and the downdate Sigma -= V_g V_g^T of ONE column chunk as ONE persistent launch over a
-// host-ordered task list (2 workgroups per CU of the stream's CU mask).  Separate launches each pay a ramp and a
-// partially filled last round -- the solve and the W update, with one tile per workgroup or less, are mostly ramp --;
-// here the W-update and downdate tiles fill in behind the solve tiles as soon as THEIR rows of V_g are stored:
-//   task               waits for                               signals
-//   solve(i, j)        --                                      vdone[i] += 1   (row block i of V_g, 128 rows)
-//   wupdate(i, c)      vdone[i] == column tiles of the chunk   --
-//   downdate(I, J)     vdone[I], vdone[J] complete             --
-// Solve tiles come first in the list and never wait, a workgroup holds one task at a time and draws it only while it
-// runs: whatever a waiting workgroup waits for has been drawn by a running workgroup that does not wait -> no deadlock;
-// waits are bounded all the same (status[3], the tile is skipped: an error code, never a hung grid).
-// Visibility across workgroups (per-XCD L2s are not coherent, MI355X guide "inter-workgroup visibility"): the storing
-// waves drain (s_waitcnt vmcnt(0)), workgroup barrier, lane 0: agent-scope release fence, drain, relaxed agent atomic
-// add; the consumer polls relaxed, then ONE agent-scope acquire fence, a drain, a workgroup barrier, plain loads.
-// The solve is an NT product here: its B operand is the TRANSPOSED chunk inverse (k_transpose_lower leaves
-// L_gg^-1 row-major next to the chain's L_gg^-T), so all three products share one tile routine and its tuning;
-// per tile the arithmetic and the K order are those of k_gemm_mfma: results are bit-identical to the separate launches.
-// ---------------------------------------------------------------------------------------
-enum : int { TASK_SOLVE = 0, TASK_WUPDATE = 1, TASK_DOWNDATE = 2 };
-constexpr int kTaskHalf = 1 << 16;              // on word 0: 64-row half tile, bi in 64-row units (downdate only)
-constexpr int kTaskTypeShift = 17;
-
-struct TaskProduct {
-  const float* A; const float* B; float* C;
-  int lda, ldb, ldc, K;
-  float alpha, beta;
-  int ktri;                                     // B lower triangular: the K loop of column tile bj stops at (bj + 1) * 128
-  int sym;                                      // lower tiles of a symmetric update: strictly-lower tiles are mirrored
-};
-struct TaskArgs {
-  TaskProduct p[3];                             // indexed by task type
-  const int* tasks;                             // two words per task: bi | half | type << 17, bj
-  int ntasks;
-  int* head;                                    // queue head (zeroed per update)
-  int* vdone;                                   // per row block of [W; nu^T]: solve tiles stored (zeroed per update)
-  int need;                                     // solve tiles per row block = column tiles of the chunk
-  int* status;
-  int stagger;
-  // Cross-launch hand-offs (the LAST chunk's launch goes out when the chain is done, without waiting for the previous
-  // chunk's launch on the other stream): its solve tiles wait for the W-update tiles of their row block in the previous
-  // launch (wprev[i] == wprev_need), its downdate tiles for the previous launch to have drained (every one of its
-  // workgroups has left: *prev_exit == prev_exit_need).  The previous launch signals both (wdone, exit_count).
-  const int* wprev; int wprev_need;
-  const int* prev_exit; int prev_exit_need;
-  int* wdone;                                   // per row block: W-update tiles stored (nullptr: nobody waits)
-  int* exit_count;                              // += 1 per workgroup that has stored its last tile (nullptr: nobody waits)
-};
-
-__device__ __forceinline__ bool task_wait(const int* counter, int need) {
-  // relaxed agent-scope polls, ~1 us apart (hundreds of pollers on one line would eat the fabric); bounded: ~0.3 s
-  for (int spin = 0; spin < (1 << 18); ++spin) {
-    if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
-    __builtin_amdgcn_s_sleep(40);
-  }
-  return false;
-}
-
-__global__ void __launch_bounds__(256, 2) k_gemm_tasks(TaskArgs g) {
-  constexpr int TM = 128, TN = 128, NQ = 8;
-  __shared__ f32x4 lds[2 * NQ * (TM + TN)];
-  int* const s_word = reinterpret_cast<int*>(lds);       // hand-over words in the first LDS slot (free between tiles)
-  const int tid = threadIdx.x;
-  if (g.stagger && blockIdx.x >= gridDim.x / 2)
-    for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  for (;;) {
-    __syncthreads();                                     // everyone is done with the previous tile (LDS, s_word)
-    if (tid == 0) {
-      const int t = atomicAdd(g.head, 1);
-      int ok = 1;
-      if (t < g.ntasks) {
-        const int w0 = g.tasks[2 * t], w1 = g.tasks[2 * t + 1];
-        const int type = w0 >> kTaskTypeShift;
-        const int rb = (w0 & kTaskHalf) ? (w0 & 0xffff) >> 1 : (w0 & 0xffff);
-        bool waited = false;
-        if (type != TASK_SOLVE) {
-          if (!task_wait(g.vdone + rb, g.need)) ok = 0;
-          if (type == TASK_DOWNDATE && w1 != rb && !task_wait(g.vdone + w1, g.need)) ok = 0;
-          if (type == TASK_DOWNDATE && g.prev_exit && !task_wait(g.prev_exit, g.prev_exit_need)) ok = 0;
-          waited = true;
-        } else if (g.wprev) {
-          if (!task_wait(g.wprev + rb, g.wprev_need)) ok = 0;
-          waited = true;
-        }
-        if (waited) {
-          if (!ok) g.status[3] = 1;
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-      }
-      s_word[0] = t;
-      s_word[1] = ok;
-    }
-    __syncthreads();
-    const int t = __builtin_amdgcn_readfirstlane(s_word[0]);
-    const int ok = __builtin_amdgcn_readfirstlane(s_word[1]);
-    if (t >= g.ntasks) break;
-    if (!ok) continue;                                   // (the leading barrier of the loop covers s_word)
-    const int w0 = __builtin_amdgcn_readfirstlane(g.tasks[2 * t]);
-    const int bj = __builtin_amdgcn_readfirstlane(g.tasks[2 * t + 1]);
-    const int type = w0 >> kTaskTypeShift;
-    const bool half = (w0 & kTaskHalf) != 0;
-    const int bi = w0 & 0xffff;
-    const TaskProduct& P = g.p[type];
-    const int tmb = half ? 64 : TM;
-    const int K = P.ktri ? min(P.K, (bj + 1) * TN) : P.K;
-    const bool mirror = P.sym && (bi * tmb >= bj * TN + TN);
-    if (half) mfma_tile<false, 64, TN, true>(P.A, P.lda, P.B, P.ldb, P.C, P.ldc, mirror, K, P.alpha, P.beta, lds, tid, bi, bj);
-    else mfma_tile<false, TM, TN, true>(P.A, P.lda, P.B, P.ldb, P.C, P.ldc, mirror, K, P.alpha, P.beta, lds, tid, bi, bj);
-    if (type == TASK_SOLVE || (type == TASK_WUPDATE && g.wdone)) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its stores of the tile have left
-      __syncthreads();
-      if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add((type == TASK_SOLVE ? g.vdone : g.wdone) + bi, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  }
-  if (g.exit_count) {                                    // this workgroup has stored its last tile
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_fetch_add(g.exit_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
-// dst[(j) * ldd + k] = src[k * lds_ + j] for the tiles k_tile <= j_tile of a w x w block (w a multiple of 32): the
-// upper-triangular chunk inverse Z_gg = L_gg^-T (strip of the factorisation) -> L_gg^-1 row-major (lower), the NT
-// operand of the fused launch's solve.  One 32 x 32 tile per workgroup through LDS, both sides coalesced.
-__global__ void __launch_bounds__(256) k_transpose_lower(const float* __restrict__ src, int lds_, float* __restrict__ dst,
-                                                         int ldd, int w) {
-  __shared__ float tile[32][33];
-  const int tj = blockIdx.x, tk = blockIdx.y;            // destination tile (rows j, columns k)
-  if (tk > tj) return;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-#pragma unroll
-  for (int r = ty; r < 32; r += 8) tile[r][tx] = src[(size_t)(tk * 32 + r) * lds_ + tj * 32 + tx];   // src rows k, columns j
-  __syncthreads();
-#pragma unroll
-  for (int r = ty; r < 32; r += 8) dst[(size_t)(tj * 32 + r) * ldd + tk * 32 + tx] = tile[tx][r];
-  (void)w;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -793,8 +793,7 @@ def test_fused_wupdate_launch_is_bit_identical(monkeypatch):
 @pytest.mark.parametrize("knobs", [
     {"EKF_SPLIT_TAIL": "0"},                                     # no half tiles at the end of the downdate's list
     {"EKF_SPLIT_TAIL": "200"},                                   # another number of half tiles
-    {"EKF_FUSED": "0"},                                          # launch per product instead of the fused chunk launches
-    {"EKF_FUSED": "0", "EKF_FUSE_WU": "0"}, {"EKF_FUSED": "0", "EKF_FUSE_WU": "2"},   # ... W update and downdate never / always in one launch
+    {"EKF_FUSE_WU": "0"}, {"EKF_FUSE_WU": "2"},                  # W update and downdate never / always in one launch
 ])
 def test_launch_structure_knobs_are_bit_identical(monkeypatch, knobs):
     """The tuning knobs of DESIGN.md section 3 change WHICH workgroup computes a tile and in what tile shape, never the
@@ -808,7 +807,7 @@ def test_launch_structure_knobs_are_bit_identical(monkeypatch, knobs):
     idx = np.arange(n_feat, dtype=np.int32)
     outs = []
     for env in ({}, knobs):
-        for k in ("EKF_SPLIT_TAIL", "EKF_FUSE_WU", "EKF_FUSED"):
+        for k in ("EKF_SPLIT_TAIL", "EKF_FUSE_WU"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)                             # read when the filter is created
