@@ -1089,7 +1089,7 @@ struct Filter : FilterBase {
         Scope sc(this, KID_CHOL_DIAG, sc_);
         if (nb == 128) {
           if constexpr (kIsF32)
-            k_chol_diag_packed<><<<1, 512, 0, sc_>>>(Ajj, ldy, Dj, d_status, std::max(1, std::min(8, (m - j + 15) / 16)));
+            k_chol_diag_packed<><<<1, 1024, 0, sc_>>>(Ajj, ldy, Dj, d_status, std::max(1, std::min(8, (m - j + 15) / 16)));
         } else {
           if constexpr (!kIsF32) {
             if (opt_mfma)

@@ -936,17 +936,23 @@ k_chol_diag(T* __restrict__ Aglob, int ld, T* __restrict__ Dinv, int* __restrict
 // the diagonal of the block.
 __device__ __forceinline__ void diag_tile_update(float* a, int LDA, int prow0, int c0, int K0, bool masked,
                                                  const float* rinv, int lr, int lq) {
+  // LDA = 132 (round 3; was 129): rows are 16-byte aligned and LDA = 4 (mod 64 banks), so (a) the operand rows come as
+  // ONE ds_read_b128 each -- lane (lr, lq) of MFMA step e multiplies k = 4 lq + e on both operands, the same k
+  // permutation on A and B --, (b) the accumulator accesses (bank 16 lq + 4 e + lr) and the column stores of the factor
+  // (bank 4 lr) are conflict-free; with 129 every access of this routine met a 4-way bank conflict, and the update of a
+  // block, not its factor, was what the first blocks waited for.
   typedef float f4 __attribute__((ext_vector_type(4)));
   f4 acc;
+  const f4 av4 = *reinterpret_cast<const f4*>(a + (prow0 + lr) * LDA + K0 + 4 * lq);
+  const f4 bv4 = *reinterpret_cast<const f4*>(a + (c0 + lr) * LDA + K0 + 4 * lq);
 #pragma unroll
   for (int e = 0; e < 4; ++e) acc[e] = a[(prow0 + 4 * lq + e) * LDA + c0 + lr];
 #pragma unroll
-  for (int s4 = 0; s4 < 4; ++s4) {
-    const int k = 4 * s4 + lq;
-    float av = a[(prow0 + lr) * LDA + K0 + k];
+  for (int e = 0; e < 4; ++e) {
+    const int k = 4 * lq + e;
+    float av = av4[e];
     if (masked) av = (k > lr) ? av : ((k == lr) ? rinv[lr] : 0.f);
-    const float bv = a[(c0 + lr) * LDA + K0 + k];
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(-av, bv, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(-av, bv4[e], acc, 0, 0, 0);
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) a[(prow0 + 4 * lq + e) * LDA + c0 + lr] = acc[e];
@@ -965,103 +971,173 @@ __device__ __forceinline__ void diag_tile_update(float* a, int LDA, int prow0, i
 // dependent chain readlane -> rsq -> scale -> MFMA is what a column costs.
 // (A substitution panel that needs no X16 was measured slower: 1.7 us per step against 0.2 us for
 // the MFMA panel + 1.15 us for the inverse.)
+#ifdef EKF_DIAG_STAMPS
+// tools/diag_bench.hip only: shader-clock stamps of wave 0 (the library is never built with this macro)
+__device__ unsigned long long ekf_diag_stamps[64];
+#define EKF_DIAG_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (K0 == 16) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); if (lane == 0) ekf_diag_stamps[i] = t_; } __builtin_amdgcn_sched_barrier(0); } while (0)
+#define EKF_KSTAMP(b, i) do { __builtin_amdgcn_sched_barrier(0); if (wave == 0) { unsigned long long t_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); if (lane == 0) ekf_diag_stamps[8 + 4 * (b) + (i)] = t_; } __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define EKF_DIAG_STAMP(i) do { } while (0)
+#define EKF_KSTAMP(b, i) do { } while (0)
+#endif
 __device__ __forceinline__ void diag_factor16(float* a, int LDA, int K0, float* x16, float* rinv, int lane,
-                                              int* status) {
+                                              int* status, float* junk16, int Kp = -1) {
+  // Round 3: a column was ~190 cycles of in-order ISSUE (24 instructions), not of latency.  Measured on the MI355X
+  // (tools/chain_latency.hip): MFMA -> v_cndmask -> v_mul -> MFMA 128 cycles, MFMA -> MFMA 40, a dependent VALU op ~16;
+  // the old column carried two VALU ops on the chain plus masks, selects and address arithmetic around it.  Now:
+  //  * block -= (row k)^T (row k) / pivot needs mask and scale on ONE operand: A = the accumulator register itself
+  //    (row k where the MFMA reads k-slot s, other rows in the other slots), B = t = that register times a per-lane
+  //    scale (-1 / pivot where lane group == s and column > k, else 0: the other slots of A multiply zeros).  What
+  //    the unmasked A adds lands in rows <= k of the block, which are never read again;
+  //  * the inverse is carried as X~ = L~^-1 of the UNIT-lower factor L~ = L D^-1 (L~[:, k] = row k / pivot): its column
+  //    update X~ -= (L~[:, k] - e_k) (row k of X~) has A = the SAME t and B = the X accumulator register unmasked
+  //    (t is zero outside lane group s): one v_mul feeds both MFMAs of a column, no select for the diagonal lane;
+  //    L^-1 = D^-1 X~ is formed once per block (rows scaled by 1 / l_kk);
+  //  * the pivot of column k+1 is known a column ahead (a[k+1][k+1] - a[k][k+1]^2 / pivot_k, two v_readlane), so rsq
+  //    and the scale vector are off the chain; L goes to LDS through per-lane-group addresses prepared once
+  //    (immediate column offset; the other lane groups aim at 16 scratch words of their own, junk16), the rows < k of a
+  //    column land in the strict upper triangle, which Z16 overwrites;
+  //  * in program order a column is: v_mul, MFMA (block), MFMA (inverse), THEN the readlanes / fma / rsq / select for the
+  //    next column -- they read the accumulator as it was before the MFMA and run in its shadow (tools/chain_latency.hip:
+  //    59 cycles for MFMA -> v_mul -> MFMA, 87 with the inverse's MFMA, 145 when the pivot path is issued in front).
   typedef float f4 __attribute__((ext_vector_type(4)));
   const int lr = lane & 15, lq = lane >> 4;
   f4 acc, xac;
+  EKF_DIAG_STAMP(0);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int r = 4 * lq + e;
     acc[e] = a[(K0 + max(r, lr)) * LDA + K0 + min(r, lr)];     // the LDS image holds the lower triangle
     xac[e] = (r == lr) ? 1.f : 0.f;
   }
-  bool bad = false;
-  float lcol[16], inv[16];
+  if (Kp >= 0) {
+    // the block's own share of the rank-16 update that follows the panel of columns Kp .. Kp + 15: block -= P P^T with
+    // P = rows K0 .. of that panel, applied straight to the registers (one LDS round trip for the block AND its update
+    // instead of tile update -> LDS -> reload); lane (lr, lq) of step s4 supplies P[lr][4 lq + s4] to both operands
+    const f4 pv = *reinterpret_cast<const f4*>(a + (K0 + lr) * LDA + Kp + 4 * lq);   // k = 4 lq + step
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(-pv[s4], pv[s4], acc, 0, 0, 0);
+  }
+  int key[4];                                    // lr in lane group s, -1 elsewhere: "column > k of group s" is one compare
+  float* colp[4];                                // L16 column store: row lr of the image in lane group s, scratch elsewhere
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    key[s] = (lq == s) ? lr : -1;
+    colp[s] = (lq == s) ? a + (K0 + lr) * LDA + K0 : junk16 + lane * 16;
+  }
+  // epilogue stores without exec-mask branches: lanes that hold no element aim at their scratch words
+  float* lp[4];                                  // L16[i = 4 lq + e][k = lr], i >= k
+  float* zp[4];                                  // Z16[lr][r = 4 lq + e] = X[r][lr], r > lr
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int r = 4 * lq + e;
+    lp[e] = (r >= lr) ? a + (K0 + r) * LDA + K0 + lr : junk16 + lane * 16 + e;
+    zp[e] = (r > lr) ? a + (K0 + lr) * LDA + K0 + r : junk16 + lane * 16 + 4 + e;
+  }
+  // pivot and -1 / pivot of column 0; inside the loop those of column k+1 are formed AFTER the MFMAs of column k have
+  // been issued, from the accumulator as it was before them.  One wave issues an instruction every ~8 cycles whatever
+  // it is (tools/chain_latency.hip: 178 cycles for a 20-instruction column with or without its readlanes / reciprocal),
+  // so a column is kept to 12 instructions: the rows go to LDS RAW and are scaled by 1 / sqrt(pivot) once per block.
+  bool below[16];                                // lane holds column lr > k of row k: 16 lane masks, formed once (SGPR pairs)
+#pragma unroll
+  for (int k = 0; k < 16; ++k) below[k] = key[k >> 2] > k;
   float pk = lane_bcast(acc[0], 0);
-  // X <- L_k^-1 X for column k: one MFMA, issued XLAG columns behind the elimination -- a wave issues in order, and
-  // an X update waiting for the previous X update would hold back the next elimination step
-  constexpr int XLAG = 3;
-  auto x_update = [&](int k) {
-    const int s = k >> 2, e = k & 3;
-    // -(v - e_k) / l_kk: v is already 0 outside rows >= k of group s
-    const float nw = ((lq == s) && (lr == k)) ? inv[k] - 1.f : -lcol[k] * inv[k];
-    const float xr = (lq == s) ? xac[e] : 0.f;
-    xac = __builtin_amdgcn_mfma_f32_16x16x4f32(nw, xr, xac, 0, 0, 0);
-  };
-  // the L16 store of a column goes out unconditionally: lanes that hold no element of it aim at the pad word of a
-  // row of the image (column 128: never read) -- no exec-mask branch per store
-  const int junk = lane * LDA + 128;
-  float my_inv = 0.f;
+  float nipk = -__builtin_amdgcn_rcpf(pk);       // -1 / pivot (a pivot <= 0: caught below from the stored diagonal)
+  __builtin_amdgcn_sched_barrier(0);
+  EKF_DIAG_STAMP(1);
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     const int s = k >> 2, e = k & 3;
-    // The dependent chain of a column: v_rsq -> v_mul -> MFMA, with the NEXT pivot computed beside the MFMA from the
-    // operands it is about to consume: a[k+1][k+1] - L[k+1][k]^2 (two readlanes, one FMA), so that its rsq is ready
-    // when the MFMA result arrives.  Everything else (the X update, the stores, the flags) is off the chain.
-    const bool low = (lq == s) && (lr >= k);
-    const float am = low ? acc[e] : 0.f;                   // row k of the block where it is column k of L
-    const float iv = __frsqrt_rn(pk);                      // (a pivot <= 0 gives NaN / inf: flagged, the caller fails)
-    if (!(pk > 0.f)) bad = true;
-    const float v = am * iv, nv = -am * iv;                // L[lr][k]; lr == k: pk * rsq(pk) = sqrt(pk)
+    // Program order = issue order (one wave issues in order, ~8-10 cycles per instruction): the reciprocal of the NEXT
+    // pivot is started right behind this column's elimination MFMA and everything that does not feed it (the inverse's
+    // MFMA, the store) is placed between it and its consumer, so that neither the ~44 cycles of MFMA -> VALU nor the ~30
+    // of the reciprocal are ever waited for: 10 instructions per column (was 24).
+    const float rk = acc[e];                     // row k of the block in lane group s, other rows elsewhere
+    const f4 prev = acc;
+    const float t = (below[k] ? rk : 0.f) * nipk;   // -L~[lr][k] for lr > k in lane group s, 0 elsewhere
+    float a10 = 0.f, a11 = 0.f;
     if (k < 15) {
       const int s1 = (k + 1) >> 2, e1 = (k + 1) & 3;
-      const float l10 = lane_bcast(v, 16 * s + k + 1);             // L[k+1][k]
-      const float a11 = lane_bcast(acc[e1], 16 * s1 + k + 1);      // a[k+1][k+1] before this column's update
-      pk = __builtin_fmaf(-l10, l10, a11);
+      a10 = lane_bcast(rk, 16 * s + k + 1);                        // a[k][k+1] = a[k+1][k], before this column's update
+      a11 = lane_bcast(prev[e1], 16 * s1 + k + 1);                 // a[k+1][k+1], likewise
     }
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(nv, v, acc, 0, 0, 0);
-    lcol[k] = v;
-    inv[k] = iv;
-    a[low ? (K0 + lr) * LDA + K0 + k : junk] = v;          // L16
-    my_inv = (lr == k) ? iv : my_inv;
-    if (k >= XLAG) x_update(k - XLAG);
+    __builtin_amdgcn_sched_barrier(0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rk, t, acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (k < 15) {
+      pk = __builtin_fmaf(a10 * nipk, a10, a11);
+      nipk = -__builtin_amdgcn_rcpf(pk);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    xac = __builtin_amdgcn_mfma_f32_16x16x4f32(t, xac[e], xac, 0, 0, 0);
+    colp[s][k] = rk;                             // raw row k = unscaled column k of L (lr < k: scratch in the upper triangle)
+    __builtin_amdgcn_sched_barrier(0);
   }
+  EKF_DIAG_STAMP(2);
+  // once per block: the pivots are the diagonal of the raw rows; L[i][k] = raw[i][k] / sqrt(pivot_k), 1 / l_kk -> rinv,
+  // X = D^-1 X~ (row r scaled by 1 / l_rr).  (LDS operations of one wave execute in order.)
+  const float dk = a[(K0 + lr) * LDA + K0 + lr];
+  float raw[4];
 #pragma unroll
-  for (int k = 16 - XLAG; k < 16; ++k) x_update(k);
-  if (bad && lane == 0) status[0] = 1;
-  if (lane < 16) rinv[lane] = my_inv;
+  for (int e = 0; e < 4; ++e) raw[e] = a[(K0 + 4 * lq + e) * LDA + K0 + lr];   // rows < lr: scratch, stored to scratch again
+  const float ivk = __frsqrt_rn(dk);
+  if (!(dk > 0.f)) status[0] = 1;                // a pivot <= 0 or NaN: the caller fails
+  rinv[lr] = ivk;                                // (the four lane groups store the same 16 values)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) *lp[e] = raw[e] * ivk;
+  const f4 irv = *reinterpret_cast<const f4*>(rinv + 4 * lq);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const int r = 4 * lq + e;                                                         // xac[e] = X[r][lr]
-    if (r > lr) a[(K0 + lr) * LDA + K0 + r] = xac[e];                                 // Z16[lr][r] = X[r][lr]
-    x16[r * 17 + lr] = xac[e];
+    const int r = 4 * lq + e;                                                         // xac[e] = X~[r][lr]
+    const float x = xac[e] * irv[e];
+    *zp[e] = x;
+    x16[r * 20 + lr] = x;                                                             // pitch 20: rows 16-byte aligned
   }
+  EKF_DIAG_STAMP(3);
 }
 
 template <int MASK = 7>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(1024)
 k_chol_diag_packed(float* __restrict__ Aglob, int ld, float* __restrict__ Dinv, int* __restrict__ status,
                    int nblk_real = 8) {
   // nblk_real: 16-column blocks that hold real rows of S; the rest of the 128 block is the identity padding of
   // the last step (L = Z = I there, decoupled from the real part) and is written back untouched.
-  constexpr int NB = 128, LDA = NB + 1, NT = 512, NBLK = NB / 16;
+  // Round 3: SIXTEEN waves.  Measured per 16-column block (tools/diag_bench.hip, s_memtime stamps of wave 0): the factoring
+  // wave needs ~2900 cycles, the seven other waves needed 3950 / 3230 / 3090 cycles for the tiles of updates 0 / 1 / 2
+  // (a 16 x 16 tile is ~30 instructions around 4 MFMAs, and one wave issues an instruction every ~8-10 cycles): the first
+  // blocks waited for the UPDATE, not for the factor.  Twelve waves share the tiles now; the waves 4, 8, 12 sit on the
+  // factoring wave's SIMD and take none (they would share its issue slots and its matrix pipe).
+  constexpr int NB = 128, LDA = NB + 4, NT = 1024, NBLK = NB / 16, NLD = NB * NB / 4 / NT;
   typedef float f4 __attribute__((ext_vector_type(4)));
-  __shared__ float a[NB * LDA];
-  __shared__ float x16[2][16 * 17];              // double-buffered: block b+1 is factored while block b's
-  __shared__ float rinv[2][16];                  // trailing update is still being applied
+  __shared__ __attribute__((aligned(16))) float a[NB * LDA];
+  __shared__ __attribute__((aligned(16))) float x16[2][16 * 20];   // double-buffered: block b+1 is factored while block b's
+  __shared__ __attribute__((aligned(16))) float rinv[2][16];       // trailing update is still being applied
+  __shared__ float junk16[64 * 16];              // store target of the lanes that hold no element of an L16 column
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: tile indices and row offsets stay in SGPRs
   const int lr = lane & 15, lq = lane >> 4;
+  const int helper = ((wave & 3) == 0) ? -1 : (wave >> 2) * 3 + (wave & 3) - 1;   // 0 .. 11 over the waves off SIMD 0
   __builtin_amdgcn_s_setprio(3);    // serial chain: win issue arbitration against co-resident tile-GEMM waves
   {
-    // 4096 float4 of the block, 8 per lane, all loads in flight before the first LDS write
-    f4 v[8];
+    // 4096 float4 of the block, all loads in flight before the first LDS write
+    f4 v[NLD];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
+    for (int p = 0; p < NLD; ++p) {
       const int q = tid + NT * p;                  // float4 index: row q / 32, columns 4 (q % 32) ..
       v[p] = *reinterpret_cast<const f4*>(Aglob + (size_t)(q >> 5) * ld + 4 * (q & 31));
     }
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
+    for (int p = 0; p < NLD; ++p) {
       const int q = tid + NT * p;
       const int i = q >> 5, j0 = 4 * (q & 31);
+      f4 w;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) a[i * LDA + j0 + e] = (j0 + e <= i) ? v[p][e] : 0.f;
+      for (int e = 0; e < 4; ++e) w[e] = (j0 + e <= i) ? v[p][e] : 0.f;
+      *reinterpret_cast<f4*>(a + i * LDA + j0) = w;
     }
   }
   __syncthreads();
-  if ((MASK & 1) && wave == 0) diag_factor16(a, LDA, 0, x16[0], rinv[0], lane, status);
+  if ((MASK & 1) && wave == 0) diag_factor16(a, LDA, 0, x16[0], rinv[0], lane, status, junk16);
   __syncthreads();
   for (int b = 0; b < NBLK; ++b) {
     const int K0 = b * 16;
@@ -1069,65 +1145,70 @@ k_chol_diag_packed(float* __restrict__ Aglob, int ld, float* __restrict__ Dinv, 
     const float* rb_inv = rinv[b & 1];
     const int nbelow = NBLK - 1 - b;                 // row blocks below the diagonal block
     // (2) panel: row blocks {below} + {Z rows of earlier blocks}: NBLK - 1 of them, P = Y X16^T
-    if ((MASK & 2) && wave < NBLK - 1) {
-      const int prow0 = (wave < nbelow) ? (K0 + 16 + wave * 16) : ((wave - nbelow) * 16);
+    if ((MASK & 2) && wave >= 1 && wave < NBLK) {
+      const int w = wave - 1;
+      const int prow0 = (w < nbelow) ? (K0 + 16 + w * 16) : ((w - nbelow) * 16);
       f4 acc = {0.f, 0.f, 0.f, 0.f};
+      const f4 av = *reinterpret_cast<const f4*>(a + (prow0 + lr) * LDA + K0 + 4 * lq);   // k = 4 lq + step on both operands
+      const f4 bv = *reinterpret_cast<const f4*>(xb + lr * 20 + 4 * lq);                  // B[k][col] = X16[col][k]
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const float av = a[(prow0 + lr) * LDA + K0 + 4 * s4 + lq];
-        const float bv = xb[lr * 17 + 4 * s4 + lq];                    // B[k][col] = X16[col][k]
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-      }
+      for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bv[s4], acc, 0, 0, 0);
 #pragma unroll
       for (int e = 0; e < 4; ++e) a[(prow0 + 4 * lq + e) * LDA + K0 + lr] = acc[e];
     }
     __syncthreads();
     if (nbelow == 0 || b + 1 >= nblk_real) break;
-    // (3a) urgent tiles: block column b+1 (what the next 16x16 factor and the next panel read): the
-    // nbelow tiles below/at the diagonal + the Z tiles of row blocks 0..b: always NBLK tiles, one per wave
-    if (MASK & 4) {
-      const bool top = wave < nbelow;
-      const int prow0 = top ? (K0 + 16 + wave * 16) : ((wave - nbelow) * 16);
-      diag_tile_update(a, LDA, prow0, K0 + 16, K0, !top && (wave - nbelow) == b, rb_inv, lr, lq);
-    }
-    // (no barrier here: wave 0's urgent tile IS the next diagonal tile, which only wave 0 goes on to read -- LDS
-    // operations of one wave execute in order --, and the remaining updates touch block columns b+2.. only)
-    // (1') wave 0 factors block b+1 while waves 1.. apply the rest of update b (block columns b+2..)
+    EKF_KSTAMP(b, 0);
+    EKF_KSTAMP(b, 1);
+    // wave 0: the next diagonal block -- its share of update b inside the registers, then elimination + inverse;
+    // the helpers: every other tile of update b meanwhile:
+    //   lower tiles (rb >= cb) of the rows below, except the diagonal block's; the Z tiles of row blocks 0 .. b (the current
+    //   block's through the mask), block column b+1 first (the next panel reads it)
     if (wave == 0) {
-      if (MASK & 1) diag_factor16(a, LDA, K0 + 16, x16[(b + 1) & 1], rinv[(b + 1) & 1], lane, status);
-    } else if (MASK & 4) {
-      const int nb1 = nbelow - 1;                  // remaining block columns
-      const int ntri = nb1 * (nb1 + 1) / 2;        // lower tiles (rb >= cb >= 1, relative to block b+1)
-      const int nz = (b + 1) * nb1;                // Z tiles: row blocks 0..b
-      for (int t = wave - 1; t < ntri + nz; t += NT / 64 - 1) {
+      if (MASK & 1) diag_factor16(a, LDA, K0 + 16, x16[(b + 1) & 1], rinv[(b + 1) & 1], lane, status, junk16, K0);
+    } else if ((MASK & 4) && helper >= 0) {
+      const int ntri = nbelow * (nbelow + 1) / 2 - 1;   // lower tiles relative to block b+1, (0, 0) is wave 0's
+      const int nz = (b + 1) * nbelow;                  // Z tiles: row blocks 0 .. b, block columns b+1 ..
+      for (int t = helper; t < ntri + nz; t += 12) {
         if (t < ntri) {
-          int rb = 0, rem = t;
-          while (rem > rb) { rem -= rb + 1; ++rb; }  // t -> (rb, cb = rem), cb <= rb
-          diag_tile_update(a, LDA, K0 + 32 + rb * 16, K0 + 32 + rem * 16, K0, false, rb_inv, lr, lq);
+          int rb = 0, rem = t + 1;
+          while (rem > rb) { rem -= rb + 1; ++rb; }     // t + 1 -> (rb, cb = rem), cb <= rb
+          diag_tile_update(a, LDA, K0 + 16 + rb * 16, K0 + 16 + rem * 16, K0, false, rb_inv, lr, lq);
         } else {
           const int u = t - ntri;
-          const int tb = u / nb1, cb = u % nb1;
-          diag_tile_update(a, LDA, tb * 16, K0 + 32 + cb * 16, K0, tb == b, rb_inv, lr, lq);
+          const int cb = u / (b + 1), tb = u % (b + 1);   // column-major: block column b+1 first
+          diag_tile_update(a, LDA, tb * 16, K0 + 16 + cb * 16, K0, tb == b, rb_inv, lr, lq);
         }
       }
     }
+    EKF_KSTAMP(b, 2);
     __syncthreads();
+    EKF_KSTAMP(b, 3);
   }
+  // L: row i, columns 4 jq ..: one 16-byte LDS read, one coalesced 16-byte store.  L^-1 = Z^T: row j of Z (strict upper
+  // storage), columns 4 iq .. as one 16-byte LDS read, stored as Dinv[4 iq + e][j] -- the lanes of a wave walk j, so
+  // each of the four stores is a coalesced 256-byte row segment (a transposed LDS read would meet 8-way conflicts).
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
+  for (int p = 0; p < NLD; ++p) {
     const int q = tid + NT * p;
     const int i = q >> 5, j0 = 4 * (q & 31);
-    f4 lo, di;
+    const f4 l = *reinterpret_cast<const f4*>(a + i * LDA + j0);
+    f4 lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) lo[e] = (j0 + e <= i) ? l[e] : 0.f;
+    *reinterpret_cast<f4*>(Aglob + (size_t)i * ld + j0) = lo;
+  }
+#pragma unroll
+  for (int p = 0; p < NLD; ++p) {
+    const int q = tid + NT * p;
+    const int j = q & 127, i0 = 4 * (q >> 7);
+    const f4 z = *reinterpret_cast<const f4*>(a + j * LDA + i0);
+    const float ljj = a[j * LDA + j];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int j = j0 + e;
-      const float l = a[i * LDA + j];
-      lo[e] = (j <= i) ? l : 0.f;
-      // Linv[i][j] = Z[j][i] (j < i: strict upper storage), 1 / L[i][i] on the diagonal
-      di[e] = (j < i) ? a[j * LDA + i] : ((j == i) ? 1.f / l : 0.f);
+      const int i = i0 + e;
+      Dinv[(size_t)i * NB + j] = (j < i) ? z[e] : ((j == i) ? 1.f / ljj : 0.f);   // Linv[i][j] = Z[j][i]
     }
-    *reinterpret_cast<f4*>(Aglob + (size_t)i * ld + j0) = lo;
-    *reinterpret_cast<f4*>(Dinv + (size_t)i * NB + j0) = di;
   }
 }
 

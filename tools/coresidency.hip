@@ -42,7 +42,7 @@ int main() {
     // give the GEMM a head start, then time the diag kernel on the other stream
     for (volatile int spin = 0; spin < 2000000; ++spin) {}
     hipEventRecord(e0, sa);
-    k_chol_diag_packed<><<<1, 512, 0, sa>>>(A, 2048, D, st);
+    k_chol_diag_packed<><<<1, 1024, 0, sa>>>(A, 2048, D, st);
     hipEventRecord(e1, sa);
     hipDeviceSynchronize();
     float md, mg = 0; hipEventElapsedTime(&md, e0, e1); if (wgs) hipEventElapsedTime(&mg, g0, g1);
