@@ -547,9 +547,10 @@ def test_points_table_with_archived_patches(dtype):
     ri, nf = g.featureIds()
     assert list(ri) == [ft.real_index for ft in ref.features] == list(range(1, 15))
     assert list(nf) == [ft.n_find for ft in ref.features] and max(nf) == 7
-    for i in (1, 4, 6, 9):                               # make four features pass the linearity test
-        p = ref.features[i].position_in_state
-        ref.Sigma[p + 5, p + 5] = 1e-9
+    for i in (1, 4, 6, 9):                               # make four features pass the linearity test: shrink rho's
+        p = ref.features[i].position_in_state            # row AND column (a congruence: Sigma stays positive, the
+        ref.Sigma[p + 5, :] *= 1e-4                      # updates that follow must still factorise S)
+        ref.Sigma[:, p + 5] *= 1e-4
     g.setFullState(ref.mu)
     g.setSigmaBlock(ref.Sigma)
     assert ref.convert2xyz_if_linear_all() == 4 and g.convert2XYZ_ifLinearAll() == 4
