@@ -549,6 +549,7 @@ struct Filter : FilterBase {
   }
   int set_frame(const unsigned char* gray, int width, int height, int stride) override {
     HIPCHK(hipSetDevice(device));
+    if (sh_on) FAIL(EKF_ERR_UNSUPPORTED, "the image side (frames, templates, NCC search) is not available on a sharded filter");
     if (!gray || width <= 0 || height <= 0 || stride < width) FAIL(EKF_ERR_ARG, "bad frame");
     if (width != cam.width || height != cam.height)
       FAIL(EKF_ERR_ARG, "frame size differs from ekf_config image_width / image_height");
@@ -570,6 +571,7 @@ struct Filter : FilterBase {
   }
   int set_patch(int index, const unsigned char* data) override {
     HIPCHK(hipSetDevice(device));
+    if (sh_on) FAIL(EKF_ERR_UNSUPPORTED, "the image side (frames, templates, NCC search) is not available on a sharded filter");
     if (index < 0 || index >= N || !data) FAIL(EKF_ERR_ARG, "feature index out of range");
     int rc = ensure_image_buffers();
     if (rc) return rc;
@@ -610,6 +612,7 @@ struct Filter : FilterBase {
   }
   int find_matches(double threshold, void* z, unsigned char* found, float* score) override {
     HIPCHK(hipSetDevice(device));
+    if (sh_on) FAIL(EKF_ERR_UNSUPPORTED, "the image side (frames, templates, NCC search) is not available on a sharded filter");
     if (!have_frame) FAIL(EKF_ERR_STATE, "ekf_find_matches needs ekf_set_frame");
     if (!have_meas) FAIL(EKF_ERR_STATE, "ekf_find_matches needs the predictions of ekf_predict / ekf_measure");
     if (N == 0) return EKF_OK;
@@ -849,6 +852,19 @@ struct Filter : FilterBase {
   // consumes them except the ellipse / RANSAC kernels)
   int ensure_sd() {
     if (have_sd || N == 0) return EKF_OK;
+    if (sh_on) {
+      // a 2x2 block needs the rows of Sigma of its feature: every rank evaluates the features it owns, then the blocks
+      // are all-gathered (4 scalars per feature)
+      const int f0 = own_f0(), f1 = own_f1();
+      if (f1 > f0)
+        k_measure_sd<T><<<(16 * (f1 - f0) + 255) / 256, 256, 0, stream>>>(S(), ld, d_pos, d_coding, f0, f1, T(sigma_pixel_2),
+                                                                        d_Hc, d_Hf, d_Sd);
+      HIPCHK(hipGetLastError());
+      int rc = gather_sd(feature_tab(), nullptr);
+      if (rc) return rc;
+      have_sd = true;
+      return EKF_OK;
+    }
     k_measure_sd<T><<<(16 * N + 255) / 256, 256, 0, stream>>>(S(), ld, d_pos, d_coding, 0, N, T(sigma_pixel_2), d_Hc, d_Hf,
                                                              d_Sd);
     HIPCHK(hipGetLastError());
@@ -1124,7 +1140,16 @@ struct Filter : FilterBase {
   int update(const void* z, const int* idx, int M, int plane, bool on_device) override {
     HIPCHK(hipSetDevice(device));
     if (sh_on) {
-      if (on_device) FAIL(EKF_ERR_UNSUPPORTED, "sharded filter: the measured list must be on the host (ekf_shard_update / ekf_update)");
+      if (on_device) {
+        // the ownership split of the list is made on the host: one small D2H of the indices, z stays where it is
+        if (M < 0 || M > N) FAIL(EKF_ERR_ARG, "M out of range");
+        std::vector<int> hidx((size_t)std::max(M, 0));
+        if (M > 0) {
+          HIPCHK(hipMemcpyAsync(hidx.data(), idx, (size_t)M * sizeof(int), hipMemcpyDeviceToHost, stream));
+          HIPCHK(hipStreamSynchronize(stream));
+        }
+        return shard_update(z, hidx.data(), M, plane);
+      }
       if (M > 0 && z) HIPCHK(hipMemcpyAsync(d_z, z, (size_t)2 * M * sizeof(T), hipMemcpyHostToDevice, stream));
       return shard_update(d_z, idx, M, plane);
     }
@@ -1337,7 +1362,14 @@ struct Filter : FilterBase {
     if (M > 0) HIPCHK(hipMemcpyAsync(d_midx, idx, (size_t)M * sizeof(int), hipMemcpyHostToDevice, stream));
     sh_list.clear();
     int m = 0, m_pad = 0;
-    int rc = build_innovation(M, plane, false, &m, &m_pad);
+    int rc;
+    if (sh_on) {
+      rc = check_ascending(idx, M);
+      if (rc) return rc;
+      rc = shard_build_ws(idx, M, plane, nullptr, &m, &m_pad);       // W rows {camera, own}, own rows of S, "reassemble S"
+    } else {
+      rc = build_innovation(M, plane, false, &m, &m_pad);
+    }
     if (rc) return rc;
     std::vector<T> tmp((size_t)m * m);
     HIPCHK(hipMemcpy2DAsync(tmp.data(), (size_t)m * sizeof(T), d_Y, (size_t)ldy * sizeof(T), (size_t)m * sizeof(T), m,
@@ -1491,6 +1523,7 @@ struct Filter : FilterBase {
       if (idx[k] < 0 || idx[k] >= N) FAIL(EKF_ERR_ARG, "feature index out of range");
     int rc = sync_layout();
     if (rc) return rc;
+    if (sh_on) { rc = check_ascending(idx, M); if (rc) return rc; }
     HIPCHK(hipMemcpyAsync(d_z, z, (size_t)2 * M * sizeof(T), hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(d_midx, idx, (size_t)M * sizeof(int), hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(d_tmp, cam_before, 7 * sizeof(T), hipMemcpyHostToDevice, stream));
@@ -1501,8 +1534,20 @@ struct Filter : FilterBase {
       Scope sc(this, KID_MEASURE);
       k_measure<T><<<(M + 63) / 64, 64, 0, stream>>>(mu(), d_pos, d_coding, 0, N, cam, d_h, d_Hc, d_Hf, d_flags, d_midx, M,
                                                     d_tmp);
-      k_measure_sd<T><<<(16 * M + 255) / 256, 256, 0, stream>>>(S(), ld, d_pos, d_coding, 0, N, T(0), d_Hc, d_Hf, d_Sd,
-                                                               d_midx, M);
+      if (sh_on) {
+        // S_hi = H Sigma H^T of a listed feature needs its rows of Sigma: owner-computes, then the 2x2 blocks are gathered
+        const ShardTab lt = list_tab(idx, M);
+        const int k0 = lt.start[sh_rank], kc = lt.count[sh_rank];
+        if (kc > 0)
+          k_measure_sd<T><<<(16 * kc + 255) / 256, 256, 0, stream>>>(S(), ld, d_pos, d_coding, 0, N, T(0), d_Hc, d_Hf, d_Sd,
+                                                                    d_midx + k0, kc);
+        HIPCHK(hipGetLastError());
+        int rg = gather_sd(lt, d_midx);
+        if (rg) return rg;
+      } else {
+        k_measure_sd<T><<<(16 * M + 255) / 256, 256, 0, stream>>>(S(), ld, d_pos, d_coding, 0, N, T(0), d_Hc, d_Hf, d_Sd,
+                                                                 d_midx, M);
+      }
       k_chi2_gate<T><<<(M + 127) / 128, 128, 0, stream>>>(d_h, d_Sd, d_z, d_midx, M, T(thr), d_out);
     }
     HIPCHK(hipMemcpyAsync(out, d_out, M, hipMemcpyDeviceToHost, stream));
@@ -1596,6 +1641,7 @@ struct Filter : FilterBase {
     sh_list.clear();
     int m = 0, m_pad = 0;
     { int rcs = ensure_sd(); if (rcs) return rcs; }
+    if (sh_on) return shard_ransac(idx, M, thr, counts, inl, best);
     int rc = build_innovation(M, 0, false, &m, &m_pad);       // W = Sigma H^T for the listed features
     if (rc) return rc;
     have_update = false;
@@ -1655,7 +1701,6 @@ struct Filter : FilterBase {
   int update_two_stage(const void* z_, const int* idx, int M, int plane, unsigned int seed, double thr, double chi2,
                        unsigned char* is_li, unsigned char* is_hi, int* hyp_drawn) override {
     HIPCHK(hipSetDevice(device));
-    if (sh_on) FAIL(EKF_ERR_UNSUPPORTED, "ekf_update_two_stage is not available on a sharded filter");
     if (M < 0 || M > N) FAIL(EKF_ERR_ARG, "M out of range");
     if (!have_meas) FAIL(EKF_ERR_STATE, "ekf_update_two_stage needs the h / H of ekf_predict");
     const T* z = static_cast<const T*>(z_);
@@ -1689,8 +1734,8 @@ struct Filter : FilterBase {
       } else {
         drawn = M;
       }
-      HIPCHK(hipMemcpy2DAsync(li.data(), 1, d_rmask + sel, (size_t)M, 1, M, hipMemcpyDeviceToHost, stream));
-      HIPCHK(hipStreamSynchronize(stream));
+      rc = fetch_mask_column(sel, idx, M, li.data());
+      if (rc) return rc;
     }
     T cam_before[7];
     HIPCHK(hipMemcpyAsync(cam_before, mu(), sizeof(cam_before), hipMemcpyDeviceToHost, stream));
@@ -1825,6 +1870,214 @@ struct Filter : FilterBase {
     ShardTab t{sh_world, sh_rank, {}, {}};
     for (int g = 0; g < sh_world; ++g) { t.start[g] = sh_fb[g]; t.count[g] = sh_fb[g + 1] - sh_fb[g]; }
     return t;
+  }
+
+  int check_ascending(const int* idx, int M) {
+    for (int k = 1; k < M; ++k)
+      if (idx[k - 1] >= idx[k]) FAIL(EKF_ERR_ARG, "sharded filter: measured indices must be strictly ascending");
+    return EKF_OK;
+  }
+  // list positions [start, start + count) of every rank's features in an ascending measured list
+  ShardTab list_tab(const int* idx, int M) const {
+    ShardTab t{sh_world, sh_rank, {}, {}};
+    int k = 0;
+    for (int g = 0; g < sh_world; ++g) {
+      while (k < M && idx[k] < sh_fb[g]) ++k;
+      int e = k;
+      while (e < M && idx[e] < sh_fb[g + 1]) ++e;
+      t.start[g] = k;
+      t.count[g] = e - k;
+      k = e;
+    }
+    return t;
+  }
+  // all-gather of 2x2 blocks: tab counts FEATURES (list == nullptr: feature indices, else positions of `list`)
+  int gather_sd(const ShardTab& tab, const int* list) {
+    if (!exchanges()) return EKF_OK;
+    int mx = 0;
+    for (int g = 0; g < sh_world; ++g) mx = std::max(mx, tab.count[g]);
+    if (mx == 0) return EKF_OK;
+    const size_t slot = (size_t)4 * mx;
+    int rc = ensure_stage(slot);
+    if (rc) return rc;
+    const int own = tab.count[sh_rank];
+    if (own > 0) k_pack_sd<T><<<(4 * own + 255) / 256, 256, 0, stream>>>(d_Sd, list, tab.start[sh_rank], own, d_stage_send);
+    rc = all_gather(slot, stream);
+    if (rc) return rc;
+    k_unpack_sd<T><<<dim3((4 * mx + 255) / 256, sh_world), 256, 0, stream>>>(d_stage_recv, slot, list, d_Sd, tab);
+    HIPCHK(hipGetLastError());
+    return EKF_OK;
+  }
+  // raw bytes of every rank (own_bytes <= slot_bytes each) -> host buffer of world x slot_bytes
+  int gather_bytes_to_host(const void* d_own, size_t own_bytes, size_t slot_bytes, std::vector<unsigned char>& host) {
+    const size_t slot = (slot_bytes + sizeof(T) - 1) / sizeof(T);
+    int rc = ensure_stage(slot);
+    if (rc) return rc;
+    if (own_bytes) HIPCHK(hipMemcpyAsync(d_stage_send, d_own, own_bytes, hipMemcpyDeviceToDevice, stream));
+    host.assign((size_t)sh_world * stage_bytes_of(slot), 0);
+    if (exchanges()) {
+      rc = all_gather(slot, stream);
+      if (rc) return rc;
+      HIPCHK(hipMemcpyAsync(host.data(), d_stage_recv, (size_t)sh_world * stage_bytes_of(slot), hipMemcpyDeviceToHost, stream));
+    } else {
+      HIPCHK(hipMemcpyAsync(host.data(), d_stage_send, stage_bytes_of(slot), hipMemcpyDeviceToHost, stream));
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    return EKF_OK;
+  }
+  static size_t stage_bytes_of(size_t slot_elems) { return slot_elems * sizeof(T); }
+
+  // W rows {camera, own} for the measured list resident in d_midx, the own rows of S (+ plane / padding rows), and the
+  // all-gather of the rows of S ("reassemble S"); d_zz != nullptr: the innovation nu and the queue heads as well
+  int shard_build_ws(const int* idx, int M, int plane, const T* d_zz, int* m_out, int* m_pad_out) {
+    const int nb = NB();
+    const int m = 2 * M + (plane ? 3 : 0), m_pad = round_up(m, nb);
+    const int npad_live = round_up(n, nb);
+    T* nu_row = d_W + (size_t)ldy * npad_live;
+    if (w_zeroed_n != n) {
+      HIPCHK(hipMemsetAsync(d_W + (size_t)n * ldy, 0, (size_t)(npad_live - n + nb) * ldy * sizeof(T), stream));
+      // the pad rows [n, npad_live) of V are the B operand of every rank's downdate, but only the rank whose tile-padded
+      // panel reaches them ever solves them: everywhere else they must be cleared when n shrinks, or rows gathered in
+      // earlier frames would be subtracted into the zero padding of Sigma (ADVICE r2)
+      if (npad_live > n)
+        HIPCHK(hipMemsetAsync(d_V + (size_t)n * ldy, 0, (size_t)(npad_live - n) * ldy * sizeof(T), stream));
+      w_zeroed_n = n;
+    }
+    const int f0 = own_f0(), f1 = own_f1();
+    const int r0 = row_of_feature(f0), r1 = row_of_feature(f1);
+    ShardTab stab = list_tab(idx, M);
+    const int k0 = stab.start[sh_rank], k1 = k0 + stab.count[sh_rank];
+    for (int g = 0; g < sh_world; ++g) { stab.start[g] *= 2; stab.count[g] *= 2; }      // rows of S
+    if (d_zz) {
+      Scope sc(this, KID_INNOVATION);
+      k_innovation<T><<<(std::max(m_pad, 64) + 255) / 256, 256, 0, stream>>>(d_zz, d_h, d_midx, M, plane, mu(), nu_row, m_pad,
+                                                                          d_counters, N, d_status);
+      counter_next = 0;
+    }
+    {
+      Scope sc(this, KID_SIGMA_HT);                        // W rows {camera, own}
+      constexpr int RB = 32;
+      dim3 g1((m_pad / 2 + 255) / 256, (camera_dim + RB - 1) / RB);
+      k_sigma_ht<T, RB><<<g1, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane, d_W, ldy,
+                                              m_pad, 0, camera_dim, N);
+      if (r1 > r0) {
+        dim3 g2((m_pad / 2 + 255) / 256, (r1 - r0 + RB - 1) / RB);
+        k_sigma_ht<T, RB><<<g2, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane, d_W, ldy,
+                                                m_pad, r0, r1, N);
+      }
+    }
+    {
+      Scope sc(this, KID_INNOVATION_COV);                  // S rows of the own measured features + the plane / padding rows
+      constexpr int KB = 8;
+      dim3 grid((m_pad + 255) / 256, std::max(1, (k1 - k0 + KB - 1) / KB) + (m_pad - 2 * M + 7) / 8);
+      k_innovation_cov<T, KB><<<grid, 256, 0, stream>>>(d_W, ldy, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane,
+                                                      T(sigma_pixel_2), T(0.00001), d_Y, m_pad, k0, k1,
+                                                      static_cast<T*>(nullptr), N);
+    }
+    HIPCHK(hipGetLastError());
+    int rc = exchange_rows(d_Y, ldy, stab, 0, m_pad, stream, KID_GATHER_S);     // "reassemble S"
+    if (rc) return rc;
+    *m_out = m;
+    *m_pad_out = m_pad;
+    return EKF_OK;
+  }
+
+  // 1-point RANSAC under sharding (vR.cpp:986-1034): hypothesis k needs W[:, 2k:2k+2] on the rows of the feature it
+  // re-projects -- a rank evaluates EVERY hypothesis on the listed features it owns (its rows of W), the partial inlier
+  // counts are all-gathered and summed; the inlier column of one hypothesis is gathered the same way (fetch_mask_column)
+  int shard_ransac(const int* idx, int M, double thr, int* counts, unsigned char* inl, int* best) {
+    int rc = check_ascending(idx, M);
+    if (rc) return rc;
+    int m = 0, m_pad = 0;
+    {
+      // W rows {camera, own} only (no S): the sigma_ht half of shard_build_ws
+      const int nb = NB();
+      m = 2 * M; m_pad = round_up(m, nb);
+      const int npad_live = round_up(n, nb);
+      if (w_zeroed_n != n) {
+        HIPCHK(hipMemsetAsync(d_W + (size_t)n * ldy, 0, (size_t)(npad_live - n + nb) * ldy * sizeof(T), stream));
+        if (npad_live > n)
+          HIPCHK(hipMemsetAsync(d_V + (size_t)n * ldy, 0, (size_t)(npad_live - n) * ldy * sizeof(T), stream));
+        w_zeroed_n = n;
+      }
+      const int r0 = row_of_feature(own_f0()), r1 = row_of_feature(own_f1());
+      Scope sc(this, KID_SIGMA_HT);
+      constexpr int RB = 32;
+      dim3 g1((m_pad / 2 + 255) / 256, (camera_dim + RB - 1) / RB);
+      k_sigma_ht<T, RB><<<g1, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, 0, d_W, ldy, m_pad, 0,
+                                              camera_dim, N);
+      if (r1 > r0) {
+        dim3 g2((m_pad / 2 + 255) / 256, (r1 - r0 + RB - 1) / RB);
+        k_sigma_ht<T, RB><<<g2, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, 0, d_W, ldy, m_pad,
+                                                r0, r1, N);
+      }
+    }
+    have_update = false;
+    if (!d_ibuf) HIPCHK(hipMalloc(&d_ibuf, (size_t)std::max(capN, 1) * 3 * sizeof(int)));
+    if ((size_t)M * M > rmask_bytes) {
+      if (d_rmask) HIPCHK(hipFree(d_rmask));
+      d_rmask = nullptr;
+      HIPCHK(hipMalloc(&d_rmask, (size_t)M * M));
+      rmask_bytes = (size_t)M * M;
+    }
+    const ShardTab lt = list_tab(idx, M);
+    const int k0 = lt.start[sh_rank], kc = lt.count[sh_rank];
+    {
+      Scope sc(this, KID_MISC);
+      if (kc > 0) {
+        dim3 grid((M + 127) / 128, kc);
+        k_ransac_eval<T><<<grid, 128, 0, stream>>>(mu(), d_W, ldy, d_Sd, d_h, d_z, d_pos, d_coding, d_midx, M, cam, T(thr),
+                                                  d_rmask, k0);
+      }
+      k_ransac_count<<<(M + 127) / 128, 128, 0, stream>>>(d_rmask, M, d_ibuf, k0, k0 + kc);
+    }
+    HIPCHK(hipGetLastError());
+    std::vector<unsigned char> host;
+    rc = gather_bytes_to_host(d_ibuf, (size_t)M * sizeof(int), (size_t)M * sizeof(int), host);
+    if (rc) return rc;
+    const size_t slot_b = host.size() / sh_world;
+    std::vector<int> cnt(M, 0);
+    const int parts = exchanges() ? sh_world : 1;
+    for (int g = 0; g < parts; ++g) {
+      const int* p = reinterpret_cast<const int*>(host.data() + (size_t)g * slot_b);
+      for (int k = 0; k < M; ++k) cnt[k] += p[k];
+    }
+    int b = 0;
+    for (int k = 1; k < M; ++k) if (cnt[k] > cnt[b]) b = k;
+    if (counts) for (int k = 0; k < M; ++k) counts[k] = cnt[k];
+    if (best) *best = b;
+    if (inl) return fetch_mask_column(b, idx, M, inl);
+    return EKF_OK;
+  }
+
+  // column `sel` of the inlier mask of the last ekf_ransac_1point (rows = list positions); under sharding every rank
+  // contributes the rows of its own listed features
+  int fetch_mask_column(int sel, const int* idx, int M, unsigned char* out) {
+    if (!sh_on) {
+      HIPCHK(hipMemcpy2DAsync(out, 1, d_rmask + sel, (size_t)M, 1, M, hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+      return EKF_OK;
+    }
+    const ShardTab lt = list_tab(idx, M);
+    int mx = 0;
+    for (int g = 0; g < sh_world; ++g) mx = std::max(mx, lt.count[g]);
+    const int k0 = lt.start[sh_rank], kc = lt.count[sh_rank];
+    const size_t slot_bytes = (size_t)std::max(mx, 1);
+    int rc = ensure_stage((slot_bytes + sizeof(T) - 1) / sizeof(T));
+    if (rc) return rc;
+    unsigned char* d_col = reinterpret_cast<unsigned char*>(d_ibuf) + (size_t)M * sizeof(int);   // behind the counts
+    if (kc > 0) k_pack_mask_col<<<(kc + 255) / 256, 256, 0, stream>>>(d_rmask, M, sel, k0, kc, d_col);
+    HIPCHK(hipGetLastError());
+    std::vector<unsigned char> host;
+    rc = gather_bytes_to_host(d_col, (size_t)kc, slot_bytes, host);
+    if (rc) return rc;
+    const size_t slot_b = host.size() / sh_world;
+    if (exchanges()) {
+      for (int g = 0; g < sh_world; ++g) memcpy(out + lt.start[g], host.data() + (size_t)g * slot_b, (size_t)lt.count[g]);
+    } else {
+      memcpy(out, host.data(), (size_t)M);
+    }
+    return EKF_OK;
   }
 
   int shard_configure(int rank, int world, ekf_allgather_fn fn, void* ctx) override {
@@ -1964,18 +2217,11 @@ struct Filter : FilterBase {
     }
     const T* d_zz = static_cast<const T*>(dz);
     const int nb = NB();
-    const int m = 2 * M + (plane ? 3 : 0), m_pad = round_up(m, nb);
+    int m = 0, m_pad = 0;
     const int npad_live = round_up(n, nb);
-    T* nu_row = d_W + (size_t)ldy * npad_live;
-    if (w_zeroed_n != n) {
-      HIPCHK(hipMemsetAsync(d_W + (size_t)n * ldy, 0, (size_t)(npad_live - n + nb) * ldy * sizeof(T), stream));
-      // the pad rows [n, npad_live) of V are the B operand of every rank's downdate, but only the rank whose tile-padded
-      // panel reaches them ever solves them: everywhere else they must be cleared when n shrinks, or rows gathered in
-      // earlier frames would be subtracted into the zero padding of Sigma (ADVICE r2)
-      if (npad_live > n)
-        HIPCHK(hipMemsetAsync(d_V + (size_t)n * ldy, 0, (size_t)(npad_live - n) * ldy * sizeof(T), stream));
-      w_zeroed_n = n;
-    }
+    // nu (replicated), W rows {camera, own}, own rows of S, "reassemble S"
+    int rc = shard_build_ws(idx, M, plane, d_zz, &m, &m_pad);
+    if (rc) return rc;
     // own state rows, and the tile-padded panel [p0, p0 + prows) the tile GEMMs run on: it covers the own rows and,
     // at its ends, a few foreign ones (whose results nobody reads and the next gather overwrites); it never reaches
     // past the padded live block (row npad_live of W / V is the nu / y row)
@@ -1989,47 +2235,6 @@ struct Filter : FilterBase {
     }
     struct Rows { int r0, count; };
     const Rows ranges[3] = {{0, p0 > 0 || prows == 0 ? nb : 0}, {p0, prows}, {npad_live, nb}};
-    // list positions [k0, k1) of the own measured features (the list is ascending, ownership contiguous)
-    ShardTab stab{sh_world, sh_rank, {}, {}};
-    {
-      int k = 0;
-      for (int g = 0; g < sh_world; ++g) {
-        while (k < M && idx[k] < sh_fb[g]) ++k;
-        int e = k;
-        while (e < M && idx[e] < sh_fb[g + 1]) ++e;
-        stab.start[g] = 2 * k;
-        stab.count[g] = 2 * (e - k);
-        k = e;
-      }
-    }
-    const int k0 = stab.start[sh_rank] / 2, k1 = k0 + stab.count[sh_rank] / 2;
-    { Scope sc(this, KID_INNOVATION);
-      k_innovation<T><<<(std::max(m_pad, 64) + 255) / 256, 256, 0, stream>>>(d_zz, d_h, d_midx, M, plane, mu(), nu_row, m_pad,
-                                                                          d_counters, N, d_status);
-      counter_next = 0; }
-    {
-      Scope sc(this, KID_SIGMA_HT);                        // W rows {camera, own}
-      constexpr int RB = 32;
-      dim3 g1((m_pad / 2 + 255) / 256, (camera_dim + RB - 1) / RB);
-      k_sigma_ht<T, RB><<<g1, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane, d_W, ldy,
-                                              m_pad, 0, camera_dim, N);
-      if (r1 > r0) {
-        dim3 g2((m_pad / 2 + 255) / 256, (r1 - r0 + RB - 1) / RB);
-        k_sigma_ht<T, RB><<<g2, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane, d_W, ldy,
-                                                m_pad, r0, r1, N);
-      }
-    }
-    {
-      Scope sc(this, KID_INNOVATION_COV);                  // S rows of the own measured features + the plane / padding rows
-      constexpr int KB = 8;
-      dim3 grid((m_pad + 255) / 256, std::max(1, (k1 - k0 + KB - 1) / KB) + (m_pad - 2 * M + 7) / 8);
-      k_innovation_cov<T, KB><<<grid, 256, 0, stream>>>(d_W, ldy, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane,
-                                                      T(sigma_pixel_2), T(0.00001), d_Y, m_pad, k0, k1,
-                                                      static_cast<T*>(nullptr), N);
-    }
-    HIPCHK(hipGetLastError());
-    int rc = exchange_rows(d_Y, ldy, stab, 0, m_pad, stream, KID_GATHER_S);     // "reassemble S"
-    if (rc) return rc;
 
     // Replicated chain in column chunks; the rank's share of every chunk beside it:
     //   second stream (CU-masked):  solve V_g rows, W update rows, ... downdate of the PREVIOUS chunk

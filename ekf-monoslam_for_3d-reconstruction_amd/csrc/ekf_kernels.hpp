@@ -527,12 +527,9 @@ __global__ void k_compact_transform(const T* __restrict__ src, T* __restrict__ d
   const int si0 = map_src[ip];
   const int ci0 = map_conv[ip];
   for (int jp = blockIdx.x * blockDim.x + threadIdx.x; jp < n_new; jp += gridDim.x * blockDim.x) {
-    int si = si0, ci = ci0;
-    int sj = map_src[jp];
-    int cj = map_conv[jp];
-    // 3 x 3 block of two converted entries: Jy (S Jy^T) is symmetric only up to rounding -- evaluate the upper
-    // triangle with the roles swapped (the formula of its mirror element on a symmetric source): exactly symmetric
-    if (ci >= 0 && cj >= 0 && jp > ip) { int t = si; si = sj; sj = t; t = ci; ci = cj; cj = t; }
+    const int si = si0, ci = ci0;
+    const int sj = map_src[jp];
+    const int cj = map_conv[jp];
     T acc;
     if (ci < 0 && cj < 0) {
       acc = src[(size_t)si * ld + sj];
@@ -542,12 +539,25 @@ __global__ void k_compact_transform(const T* __restrict__ src, T* __restrict__ d
     } else if (cj < 0) {
       acc = T(0);
       for (int a = 0; a < 6; ++a) acc = t_fma(Jy[ci * 6 + a], src[(size_t)(si + a) * ld + sj], acc);
-    } else {
+    } else if (jp <= ip) {
+      // 3 x 3 block of two converted entries, lower triangle: sum_a Jy_i[a] (sum_b S[i+a][j+b] Jy_j[b])
       acc = T(0);
       for (int a = 0; a < 6; ++a) {
         T inner = T(0);
         for (int b = 0; b < 6; ++b) inner += src[(size_t)(si + a) * ld + sj + b] * Jy[cj * 6 + b];
         acc += Jy[ci * 6 + a] * inner;
+      }
+    } else {
+      // ... upper triangle: Jy (S Jy^T) is symmetric only up to rounding, so the element is evaluated in the ORDER of its
+      // mirror element -- sum_b Jy_j[b] (sum_a S[i+a][j+b] Jy_i[a]), on an exactly symmetric source the same products in
+      // the same sequence -- but from the rows of THIS entry's feature: exactly symmetric, and under row-panel sharding
+      // only rows the rank owns are read (round 2 swapped the roles and read the mirror feature's rows, which another
+      // rank may own: found by tools/rccl_smoke.py in round 3)
+      acc = T(0);
+      for (int b = 0; b < 6; ++b) {
+        T inner = T(0);
+        for (int a = 0; a < 6; ++a) inner += src[(size_t)(si + a) * ld + sj + b] * Jy[ci * 6 + a];
+        acc += Jy[cj * 6 + b] * inner;
       }
     }
     dst[(size_t)ip * ld + jp] = acc;
@@ -669,9 +679,9 @@ __global__ void k_ransac_eval(const T* __restrict__ mu, const T* __restrict__ W,
                               const T* __restrict__ Sd, const T* __restrict__ h, const T* __restrict__ z,
                               const int* __restrict__ pos, const int* __restrict__ coding,
                               const int* __restrict__ midx, int M, CamParams cam, T thr,
-                              unsigned char* __restrict__ mask) {
+                              unsigned char* __restrict__ mask, int j0 = 0) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y;
+  const int j = j0 + blockIdx.y;                 // j0 > 0: a rank evaluates the listed features it owns (their rows of W)
   if (k >= M) return;
   const int fk = midx[k], fj = midx[j];
   // g = S_k^-1 nu_k
@@ -707,11 +717,13 @@ __global__ void k_ransac_eval(const T* __restrict__ mu, const T* __restrict__ W,
   mask[(size_t)j * M + k] = (t_sqrt(e0 * e0 + e1 * e1) <= thr) ? 1 : 0;
 }
 
-__global__ void k_ransac_count(const unsigned char* __restrict__ mask, int M, int* __restrict__ counts) {
+__global__ void k_ransac_count(const unsigned char* __restrict__ mask, int M, int* __restrict__ counts, int j0 = 0,
+                               int j1 = -1) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= M) return;
+  if (j1 < 0) j1 = M;
   int c = 0;
-  for (int j = 0; j < M; ++j) c += mask[(size_t)j * M + k];
+  for (int j = j0; j < j1; ++j) c += mask[(size_t)j * M + k];    // (a rank: the features it owns -> partial counts)
   counts[k] = c;
 }
 

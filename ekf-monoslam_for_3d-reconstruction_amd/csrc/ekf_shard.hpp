@@ -101,4 +101,30 @@ __global__ void k_unpack_flags(const T* __restrict__ recv, size_t slot_elems, un
   if (i < tab.count[g]) flags[tab.start[g] + i] = (unsigned char)recv[(size_t)g * slot_elems + i];
 }
 
+// 2x2 St blocks (4 scalars per feature) of a contiguous feature range / of list positions [k0, k0 + count) of a list.
+template <typename T>
+__global__ void k_pack_sd(const T* __restrict__ Sd, const int* __restrict__ list, int first, int count, T* __restrict__ dst) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 4 * count) return;
+  const int f = list ? list[first + t / 4] : first + t / 4;
+  dst[t] = Sd[(size_t)f * 4 + (t & 3)];
+}
+template <typename T>
+__global__ void k_unpack_sd(const T* __restrict__ recv, size_t slot_elems, const int* __restrict__ list, T* __restrict__ Sd,
+                            ShardTab tab) {
+  const int g = blockIdx.y;
+  if (g == tab.self) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 4 * tab.count[g]) return;
+  const int f = list ? list[tab.start[g] + t / 4] : tab.start[g] + t / 4;
+  Sd[(size_t)f * 4 + (t & 3)] = recv[(size_t)g * slot_elems + t];
+}
+
+// column `col` of the M x M inlier mask, rows [j0, j0 + count) -> bytes
+__global__ void k_pack_mask_col(const unsigned char* __restrict__ mask, int M, int col, int j0, int count,
+                                unsigned char* __restrict__ dst) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < count) dst[t] = mask[(size_t)(j0 + t) * M + col];
+}
+
 }  // namespace ekf

@@ -1,4 +1,4 @@
-"""Test-only backend of `sharded.ShardProtocol`: the arithmetic of ONE rank on the structured oracle.
+"""Test-only backend of `shard_protocol.ShardProtocol`: the arithmetic of ONE rank on the structured oracle.
 It keeps ONLY what the rank owns valid -- the rows of Sigma of its features plus the camera rows, the W / V rows it
 computed, the per-feature records it measured -- and poisons everything else with NaN after every operation, so a
 protocol that reads a panel before the matching all-gather (or forgets one) produces NaN and fails loudly."""

@@ -1,6 +1,6 @@
 """The N > 1 path: row-panel sharding with all-gathers of H, S, V (+ linearity flags, + Sigma panels on re-balance).
 
-CPU (gloo, world_size 2 and 4): `sharded.ShardProtocol` -- the protocol the library implements, in numpy -- over an
+CPU (gloo, world_size 2 and 4): `shard_protocol.ShardProtocol` -- the protocol the library implements, in numpy -- over an
 oracle-backed rank that poisons everything it does not own: uneven partitions, measured subsets, XYZ features, the
 plane rows, add / remove / convert under sharding and the re-balance must all equal the unsharded oracle.
 GPU: the library's sharded step (csrc/ekf_capi.hip) with world 1 in-process, and with 2 / 4 ranks sharing the one GPU
@@ -135,7 +135,7 @@ def _cpu_worker(rank, world, port, n_feat, frames, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from __graft_entry__ import load_package
     load_package()
-    from ekf_monoslam_amd.sharded import ShardProtocol
+    from shard_protocol import ShardProtocol
     from sharded_common import OracleShardBackend
     holder = {}
 
@@ -179,7 +179,7 @@ def test_shard_protocol_matches_unsharded_oracle_gloo(world, n_feat):
 def test_partition_balances_rows_not_features():
     from __graft_entry__ import load_package
     load_package()
-    from ekf_monoslam_amd.sharded import partition_by_rows
+    from shard_protocol import partition_by_rows
     # 4 XYZ features (3 rows) then 4 inverse-depth ones (6 rows): half of the ROWS is after feature 5
     sizes = [3, 3, 3, 3, 6, 6, 6, 6]
     pos = list(14 + np.concatenate([[0], np.cumsum(sizes)[:-1]]))
@@ -402,6 +402,123 @@ def test_hip_shard_n1000_ranks_match_fp64_oracle(world):
         assert bound("rank own Sigma rows, feature columns, vs fp64 oracle", relf(S_rows[14:, 14:], S_ref[own][:, 14:]), 1e-4)
         seen[rows] = True
     assert seen.all()
+
+
+def _gpu_flow_worker(rank, world, port, n_feat, dtype_name, out):
+    """The reference's whole update() flow on a SHARDED filter (VERDICT r2 next #5): every piece against the oracle."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from ekf_monoslam_amd import sharded
+    dtype = np.dtype(dtype_name).type
+    flt = _mk_hip(pkg, n_feat, capacity=n_feat + 8, dtype=dtype)
+    sharded.configure(flt, rank, world)
+    ref = o.build_scenario(o.StructuredFilter, o.Config.kinect(), n_feat, dtype)
+    res = {}
+    # frame 1: the pieces one by one
+    ref.predict()
+    flt.predict()
+    vis = ref.visible_indices()
+    z = o.synthetic_measurements(ref, vis, sigma=1.0).reshape(-1, 2)
+    z[5] += 7.0                                          # outside 2 sigma_px of the prediction, inside a wide chi2 gate
+    z[9] += 60.0                                         # a gross mismatch
+    h, visg, rem, S2 = flt.predictions()                 # the 2x2 St blocks need every owner's rows: gathered
+    S2_ref = np.stack([ref.innovation_covariance([i]) for i in range(n_feat)])
+    res["S2"] = relf(S2, S2_ref)
+    res["ellipses"] = bool(np.array_equal(flt.searchEllipses(), np.array([o.ellipse_parameters(S2_ref[i], ref.cfg.sigma_size)
+                                                                           for i in range(n_feat)])))
+    St = flt.innovationCovariance(vis[::2], plane_constraint=True)
+    res["St"] = relf(St, ref.innovation_covariance(vis[::2], plane=True))
+    counts, best, inl = flt.ransac1Point(z, vis)
+    counts_ref, mask_ref = o.ransac_1point(ref, z, vis)
+    res["counts"] = bool(np.array_equal(counts, counts_ref)) and int(best) == int(np.argmax(counts_ref))
+    res["inliers"] = int((inl != mask_ref[best]).sum())
+    mu_before = ref.mu.copy()
+    cam_before = flt.getState()[:7]
+    li = [vis[k] for k in range(len(vis)) if inl[k]]
+    ref.update(z[inl].reshape(-1), li)
+    flt.update(z[inl].reshape(-1), li)
+    rest = [vis[k] for k in range(len(vis)) if not inl[k]]
+    hi_ref, chi2 = o.rescue_high_innovation(ref, mu_before, z[~inl], rest, return_chi2=True)
+    thr = float(np.sqrt(chi2[rest.index(vis[5])] * chi2[rest.index(vis[9])]))
+    hi_ref = o.rescue_high_innovation(ref, mu_before, z[~inl], rest, threshold=thr)
+    hi = flt.rescueHighInnovation(cam_before, z[~inl], rest, thr)
+    res["rescue"] = list(map(bool, hi)) == list(map(bool, hi_ref)) and bool(hi[rest.index(vis[5])]) and not bool(hi[rest.index(vis[9])])
+    sel = [rest[k] for k in range(len(rest)) if hi[k]]
+    zz = z[~inl][np.asarray(hi, bool)].reshape(-1)
+    ref.update(zz, sel)
+    # (device-resident list under sharding: the same update through ekf_update_device)
+    d_z = torch.from_numpy(np.ascontiguousarray(zz, dtype)).cuda()
+    d_i = torch.from_numpy(np.asarray(sel, np.int32)).cuda()
+    flt.update_device(d_z.data_ptr(), d_i.data_ptr(), len(sel))
+    # frames 2-3: the composite call, with the reference's draw loop (seed) and the plane rows
+    for k in range(2):
+        ref.predict()
+        flt.predict()
+        vis = ref.visible_indices()
+        z = o.synthetic_measurements(ref, vis, seed=2000 + k, sigma=0.7).reshape(-1, 2)
+        z[3 + k] += 9.0
+        li_r, hi_r, drawn_r = o.update_two_stage(ref, z, vis, plane=(k == 1), seed=(0 if k == 0 else 77))
+        li_g, hi_g, drawn_g = flt.updateTwoStage(z, vis, plane_constraint=(k == 1), seed=(0 if k == 0 else 77))
+        res[f"two_stage_{k}"] = bool(np.array_equal(li_r, li_g) and np.array_equal(hi_r, hi_g) and drawn_r == drawn_g)
+    flt.synchronize()
+    info = sharded.shard_info(flt)
+    rows = np.r_[0:14, info.row_begin:info.row_end]
+    S = flt.getFullSigma()
+    res["mu"] = relf(flt.getFullState(), ref.mu)
+    res["Sigma"] = relf(S[rows], ref.Sigma[rows])
+    res["n_find"] = bool(np.array_equal(flt.featureIds()[1], [ft.n_find for ft in ref.features]))
+    try:
+        flt.setFrame(np.zeros((240, 320), np.uint8))
+        res["image_refused"] = False
+    except pkg.EkfError:
+        res["image_refused"] = True
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_hip_shard_update_flow_three_ranks_vs_oracle(dtype):
+    """A sharded filter as a drop-in for the reference's update() (vR.cpp:964-1130 + 1245-1284): 2x2 St blocks and search
+    ellipses, the full innovation covariance, the 1-point RANSAC hypotheses, the rescue gate, the device-list update and
+    the two-stage composite (best hypothesis; the reference's seeded draw loop with the plane rows) on 3 ranks sharing
+    the GPU -- every rank's answers against the oracle's."""
+    world, n_feat = 3, 26
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gpu_flow_worker, args=(world, free_port(), n_feat, np.dtype(dtype).name, out), nprocs=world, join=True)
+    f32 = dtype == np.float32
+    for rank in range(world):
+        r = out[rank]
+        assert r["ellipses"] and r["counts"] and r["inliers"] == 0 and r["rescue"], (rank, r)
+        assert r["two_stage_0"] and r["two_stage_1"] and r["n_find"] and r["image_refused"], (rank, r)
+        assert bound("rank S2x2 vs oracle", r["S2"], 2e-5 if f32 else 1e-10)
+        assert bound("rank St vs oracle", r["St"], 2e-5 if f32 else 1e-10)
+        assert bound("rank mu vs oracle", r["mu"], 5e-5 if f32 else 1e-11)
+        assert bound("rank Sigma rows vs oracle", r["Sigma"], 2e-3 if f32 else 1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_rccl_smoke_script_rehearsal_over_gloo(world):
+    """tools/rccl_smoke.py -- the one-command check a multi-GPU node runs over RCCL -- rehearsed here with `world` ranks
+    sharing the GPU (gloo): N = 200 (ten 128-row tiles: the ranks' panels do NOT span the matrix), all-measured and
+    subset + plane updates, a removal / addition, a conversion pass that shrinks n (zero padding checked on the device),
+    the two-stage update; every rank against the plain path, fp64 to 1e-8 and fp32 to 5e-3.  Regression test of the
+    round-3 finding: a converted feature's 3 x 3 cross blocks read the MIRROR feature's rows, which another rank owns."""
+    import subprocess
+    env = dict(os.environ)
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+                        os.path.join(ROOT, "tools", "rccl_smoke.py"), "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    lines = [l for l in (r.stdout + r.stderr).splitlines() if l.startswith("[rccl_smoke]")]
+    assert r.returncode == 0 and len(lines) == 2 and all(l.endswith("OK") for l in lines), (r.returncode, lines, r.stderr[-2000:])
 
 
 # BASELINE configs[4]: N = 4000, fp32, dynamic add / delete-feature covariance resize every 50 frames
