@@ -242,7 +242,7 @@ struct Filter : FilterBase {
                     d_flags, d_cflag, d_Jy, d_Yxyz, d_map_src, d_map_conv, d_Y, d_W, d_V, d_Dinv, d_z, d_midx,
                     d_status, d_tmp, d_K, d_tilemap, d_counters, d_ibuf, d_rmask, d_pts,
                     d_frame, d_patch[0], d_patch[1], d_mpatch[0], d_mpatch[1], d_hb, d_zm, d_found, d_score, d_keep,
-                    d_Vs[0], d_Vs[1], d_Vs[2], d_stage_send, d_stage_recv, d_archive, d_arch_idx};
+                    d_Vs[0], d_Vs[1], d_Vs[2], d_stage_send, d_stage_recv, d_archive, d_arch_idx, d_panel_tiles};
     for (void* p : ptrs) if (p) hipFree(p);
     if (own_stream && stream) hipStreamDestroy(stream);
     if (stream_b) hipStreamDestroy(stream_b);
@@ -1872,6 +1872,48 @@ struct Filter : FilterBase {
     return t;
   }
 
+  // Tile list of a rank's row panel [p0, p0 + prows) x [0, npad_live) for the queued downdate launch (tri = 3): a tile
+  // whose rows AND columns lie inside the own rows [r0, r1) is listed once (column tile <= row tile) and mirrored;
+  // every other tile -- the ragged first / last row tile of the panel (it holds foreign rows), the columns of other
+  // ranks -- is a plain tile.  Row tiles are relative to p0, column tiles absolute.
+  int opt_shard_sym = 1;                                   // EKF_SHARD_SYM=0: the plain row panel (A/B)
+  int* d_panel_tiles = nullptr;
+  size_t panel_tiles_cap = 0;
+  int panel_ntiles = 0;
+  std::vector<int> panel_key;
+  int ensure_panel_tiles(int p0, int prows, int r0, int r1, int npad_live) {
+    std::vector<int> key = {p0, prows, r0, r1, npad_live};
+    if (key == panel_key) return EKF_OK;
+    std::vector<int> tl;
+    const int t0 = p0 / 128, nt = prows / 128, nc = npad_live / 128;
+    auto interior = [&](int T_) { return 128 * T_ >= r0 && 128 * T_ + 128 <= r1; };
+    for (int P = 0; P < nt; ++P) {
+      const int Tg = t0 + P;
+      for (int J = 0; J < nc; ++J) {
+        if (interior(Tg) && interior(J)) {
+          if (J > Tg) continue;                            // the mirror of (J, Tg)
+          tl.push_back(J < Tg ? (P | kMirrorTile) : P);
+          tl.push_back(J);
+        } else {
+          tl.push_back(P);
+          tl.push_back(J);
+        }
+      }
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    if (stream_b) HIPCHK(hipStreamSynchronize(stream_b));
+    if (tl.size() > panel_tiles_cap) {
+      if (d_panel_tiles) HIPCHK(hipFree(d_panel_tiles));
+      d_panel_tiles = nullptr;
+      HIPCHK(hipMalloc(&d_panel_tiles, tl.size() * sizeof(int)));
+      panel_tiles_cap = tl.size();
+    }
+    HIPCHK(hipMemcpy(d_panel_tiles, tl.data(), tl.size() * sizeof(int), hipMemcpyHostToDevice));
+    panel_ntiles = (int)tl.size() / 2;
+    panel_key = key;
+    return EKF_OK;
+  }
+
   int check_ascending(const int* idx, int M) {
     for (int k = 1; k < M; ++k)
       if (idx[k - 1] >= idx[k]) FAIL(EKF_ERR_ARG, "sharded filter: measured indices must be strictly ascending");
@@ -2087,6 +2129,7 @@ struct Filter : FilterBase {
     sh_rank = rank; sh_world = world; sh_ag = fn; sh_ctx = ctx;
     sh_on = true;
     if (const char* e = getenv("EKF_SHARD_FORCE_COLLECTIVE")) sh_force = (atoi(e) != 0) && fn != nullptr;
+    if (const char* e = getenv("EKF_SHARD_SYM")) opt_shard_sym = atoi(e);
     if (!stream_g) {
       HIPCHK(hipStreamCreateWithFlags(&stream_g, hipStreamNonBlocking));
       for (auto& e : ev_gath) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -2227,14 +2270,19 @@ struct Filter : FilterBase {
     // past the padded live block (row npad_live of W / V is the nu / y row)
     const int f0 = own_f0(), f1 = own_f1();
     const int r0 = row_of_feature(f0), r1 = row_of_feature(f1);
+    // (round 3: the panel starts on a tile boundary, so that the tiles that lie INSIDE the own rows on both sides -- the
+    // own x own block of Sigma minus its ragged ends -- are computed once, as lower tiles, and mirrored: both rows of a
+    // mirrored pair are then owned.  Per rank the downdate is rows x m x (2 n - rows) flop instead of 2 rows n m.)
     int p0 = 0, prows = 0;
     if (r1 > r0) {
-      prows = round_up(r1 - r0, nb);
-      p0 = std::min(r0, npad_live - prows);
-      if (p0 < nb) { p0 = 0; prows = std::min(npad_live, round_up(r1, nb)); }
+      p0 = r0 / nb * nb;
+      prows = round_up(r1, nb) - p0;
     }
     struct Rows { int r0, count; };
     const Rows ranges[3] = {{0, p0 > 0 || prows == 0 ? nb : 0}, {p0, prows}, {npad_live, nb}};
+    bool sym_panel = false;
+    if constexpr (kIsF32) sym_panel = opt_mfma && nb == 128 && prows > 0 && opt_shard_sym;
+    if (sym_panel) { rc = ensure_panel_tiles(p0, prows, r0, r1, npad_live); if (rc) return rc; }
 
     // Replicated chain in column chunks; the rank's share of every chunk beside it:
     //   second stream (CU-masked):  solve V_g rows, W update rows, ... downdate of the PREVIOUS chunk
@@ -2284,6 +2332,13 @@ struct Filter : FilterBase {
         const Rows& rr = ranges[q];
         if (rr.count == 0) continue;
         Scope sc(this, KID_DOWNDATE, ss);
+        if (q == 1 && sym_panel && counter_next + 8 <= kQueueCounters) {
+          // the own panel as ONE queued launch over the listed tiles: interior x interior lower tiles + mirror, the rest plain
+          if (sc.on) prof_work[KID_DOWNDATE] += 2.0 * 128 * 128 * panel_ntiles * double(std::min(c1, m) - std::min(c0, m));
+          gemm<ROLE_DOWNDATE, false>(d_V + (size_t)rr.r0 * ldy + c0, ldy, d_V + c0, ldy, S() + (size_t)rr.r0 * ld, ld, rr.count,
+                                     npad_live, c1 - c0, T(-1), T(1), 3, rr.r0, 0, 0, 0, ss, d_panel_tiles, panel_ntiles);
+          continue;
+        }
         if (sc.on) prof_work[KID_DOWNDATE] += 2.0 * rr.count * double(n) * (std::min(c1, m) - std::min(c0, m));
         gemm<ROLE_DOWNDATE, false>(d_V + (size_t)rr.r0 * ldy + c0, ldy, d_V + c0, ldy, S() + (size_t)rr.r0 * ld, ld, rr.count,
                                    npad_live, c1 - c0, T(-1), T(1), 0, 0, 0, 0, 0, ss);

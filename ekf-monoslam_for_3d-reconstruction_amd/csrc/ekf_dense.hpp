@@ -214,7 +214,8 @@ __global__ void k_innovation_cov(const T* __restrict__ W, int ldy,
 //   BT = true  ("NN"): B is K x cols row-major, C[i][j] = sum_k A[i][k] B[k][j]
 //   tri: 0 = every tile; 1 = skip tiles strictly above the diagonal, the diagonal being
 //        (row_off + i == col_off + j); 2 = as 1 and mirror every strictly-lower tile into
-//        C^T (symmetric rank-K update).
+//        C^T (symmetric rank-K update); 3 = (queued 128 x 128 downdate launches only) every listed tile is computed, the
+//        ones flagged kMirrorTile are mirrored -- the row panel of a rank whose own x own block is symmetric.
 //   ktri: 1 = op(B) is upper-triangular in (k, j) (zero for k > j): the K loop of column tile
 //        bj stops at (bj + ktile_off + 1)*TS.
 // ROLE only tags the instantiation so that rocprofv3 lists each use of the tile kernel under
@@ -249,6 +250,7 @@ struct GemmArgs {
 };
 constexpr int kSecondProduct = 0x10000;         // flag on bj for a tile of the second product
 constexpr int kHalfTile = 0x20000;              // flag on bi: 64-row half tile, bi & 0xffff in 64-row units (k_gemm_mfma, downdate)
+constexpr int kMirrorTile = 0x40000;            // flag on bi, tri == 3 (tiles taken as listed): also store the transposed tile
 
 // Next tile of this workgroup: plain 2-D grid (one tile, then done) or the work queue.
 __device__ __forceinline__ bool gemm_next_tile(const GemmArgs& g, int* s_tile, int& iter, int& bi, int& bj) {
@@ -394,6 +396,7 @@ __global__ void __launch_bounds__(256, (ROLE == ROLE_TRAILING && TM == 64 && TN 
     for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   int bi, bj, iter = 0;
   while (gemm_next_tile(g, s_tile_p, iter, bi, bj)) {
+  bool listed_mirror = false;
   auto tile_body = [&](auto tm_tag) {
   constexpr int TMb = decltype(tm_tag)::value, MI = TMb / 64, PA = TMb * 8 / NT;
   const bool second = DUAL && (bj & kSecondProduct);
@@ -403,7 +406,7 @@ __global__ void __launch_bounds__(256, (ROLE == ROLE_TRAILING && TM == 64 && TN 
   const int ldb = second ? g.ldb2 : g.ldb, ldc = second ? g.ldc2 : g.ldc;
   const int tri = second ? 0 : g.tri;
   const int grow0 = g.row_off + bi * TMb, gcol0 = g.col_off + bj * TN;
-  if (tri && grow0 + TMb <= gcol0) return;
+  if (tri && tri != 3 && grow0 + TMb <= gcol0) return;
   if (g.zrow && grow0 >= g.zrow && gcol0 >= g.zcol_end) return;
   const int K = g.ktri ? min(g.K, (bj + g.ktile_off + 1) * TN) : g.K;
   // A staging: TMb*8 float4 per tile, PA per lane; 8 consecutive lanes cover 128 B of a row
@@ -557,7 +560,7 @@ __global__ void __launch_bounds__(256, (ROLE == ROLE_TRAILING && TM == 64 && TN 
     kstep(no{}, no{}, k0);
   }
   // epilogue: acc reg e of lane -> row (e&3) + 8*(e>>2) + 4*h, col l31 of the 32x32 tile
-  const bool mirror = (TMb == TN || SPLIT) && (tri == 2) && (grow0 >= gcol0 + TN);
+  const bool mirror = (TMb == TN || SPLIT) && ((tri == 2 && grow0 >= gcol0 + TN) || (tri == 3 && listed_mirror));
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -589,6 +592,8 @@ __global__ void __launch_bounds__(256, (ROLE == ROLE_TRAILING && TM == 64 && TN 
     }
   };
   if constexpr (SPLIT) {
+    listed_mirror = (bi & kMirrorTile) != 0;
+    bi &= ~kMirrorTile;
     if (bi & kHalfTile) {
       bi &= ~kHalfTile;
       tile_body(std::integral_constant<int, 64>{});
