@@ -406,7 +406,7 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
         pmc, pmc_note = LIVE_PMC
     elif LIVE_PMC[1]:
         pmc_note = LIVE_PMC[1]
-    for tag in (() if pmc else ("r2", "r1")):
+    for tag in (() if pmc else ("r3", "r2", "r1")):
         pmc_path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
         if n_feat == 1000 and os.path.exists(pmc_path):
             doc = json.load(open(pmc_path))
@@ -487,9 +487,42 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
         run32(args.warmup, args.steps)
         flt3.synchronize()
         t1 = time.perf_counter()
+        t32 = (t1 - t0) / args.steps
+        b32 = 3.0 * n * n * 4 + 4.0 * n * 2 * m32 * 4        # Sigma read for W, read + written by the downdate; W, V
         result["secondary_M32"] = {"measured_per_frame": m32, "value": round(args.steps / (t1 - t0), 2),
-                                   "unit": "updates/s", "ms_per_step": round(1e3 * (t1 - t0) / args.steps, 4)}
+                                   "unit": "updates/s", "ms_per_step": round(1e3 * t32, 4),
+                                   "roofline": {"bound": "hbm", "achieved": round(b32 / t32 / 1e9, 1), "peak": PEAK_HBM_GBS,
+                                                "unit": "GB/s", "frac": round(b32 / t32 / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+                                                "basis": "whole step: algorithmic bytes 3 n^2 s + 4 n 2M s (rank-64 update: the "
+                                                         "contractions are below the MFMA / HBM crossover, SURVEY 8d) / ms_per_step",
+                                                "algorithmic_bytes_per_step": b32}}
         flt3.close()
+
+        if n_feat < 600:
+            # small maps (configs[1], N = 200) are LATENCY-bound: one column chunk, a serial chain of a few block steps and
+            # ~20 launches per step; say so with numbers next to the MFMA roofline of the (tiny) downdate
+            flt6 = FilterRing(pkg, cfg, n_feat, px0, z, min(frames, 60))
+            flt6.set_option(2, 2)                            # HIP events around every kernel (adds launch gaps: shares only)
+            flt6.profile_reset()
+            k6 = min(40, frames)
+            run_steps(flt6, d_z, d_idx, n_feat, 0, k6, bpf)
+            flt6.synchronize()
+            p6 = flt6.profile()
+            flt6.set_option(2, 0)
+            per = {kname: (ms / k6, cnt / k6) for kname, (ms, cnt) in p6.items() if cnt}
+            chain = sum(per.get(kname, (0.0, 0))[0] for kname in ("chol_diag", "chol_panel", "chol_trailing"))
+            bytes_step = 3.0 * n * n * 4 + 4.0 * n * 2 * n_feat * 4 + 2.0 * (2 * n_feat) ** 2 * 4
+            result["roofline_step"] = {
+                "bound": "latency", "achieved": round(bytes_step / (ms_per_step * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
+                "unit": "GB/s", "frac": round(bytes_step / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+                "basis": "whole step: algorithmic bytes 3 n^2 s + 4 n m s + 2 m^2 s / ms_per_step -- far from either roofline: "
+                         "the step is the sum of its launch latencies",
+                "launches_per_step": round(sum(c for _, c in per.values()), 1),
+                "chain_block_steps": int(round(per.get("chol_diag", (0.0, 0))[1])),
+                "chain_kernel_ms_per_step": round(chain, 4),
+                "chain_share_of_kernel_time": round(chain / max(sum(v for v, _ in per.values()), 1e-9), 3),
+                "kernel_ms_per_step": {kname: round(v, 4) for kname, (v, _) in sorted(per.items(), key=lambda kv: -kv[1][0])[:8]}}
+            flt6.close()
 
         if n_feat >= 600 and not args.split_bf16:
             # opt-in variant (NOT the headline, not the default): the covariance downdate on the bf16 matrix pipe
