@@ -348,9 +348,13 @@ typedef struct ekf_shard_info {
 /* Switches the filter to sharded operation.  Call it at a point where every rank holds the same, fully valid
  * filter (e.g. right after the identical construction of the map).  From then on ekf_predict, ekf_update (host
  * z / indices), ekf_add_feature, ekf_remove_feature(s) and ekf_convert_xyz_if_linear(_all) run the sharded step;
- * getters of Sigma are valid for the camera rows and the own rows only (ekf_shard_rebalance makes all rows valid);
- * ekf_update_device, ekf_ransac_1point, ekf_rescue_high_innovation, ekf_innovation_covariance and the image side
- * are not available on a sharded filter.  world = 1 needs no callback. */
+ * getters of Sigma are valid for the camera rows and the own rows only (ekf_shard_rebalance makes all rows valid).
+ * Round 3: the whole update() flow runs sharded as well -- ekf_update_device (the list is copied to the host once),
+ * ekf_update_two_stage, ekf_ransac_1point (every rank evaluates the hypotheses on the listed features it owns, the
+ * partial inlier counts are all-gathered), ekf_rescue_high_innovation and the 2x2 St blocks behind ekf_get_predictions /
+ * ekf_get_search_ellipses (owner-computes, the blocks are all-gathered), ekf_innovation_covariance; under sharding their
+ * measured lists must be strictly ascending.  The image side (ekf_set_frame, ekf_set_patch, ekf_find_matches) is
+ * refused with EKF_ERR_UNSUPPORTED.  world = 1 needs no callback. */
 int ekf_shard_configure(ekf_filter* f, int rank, int world, ekf_allgather_fn allgather, void* ctx);
 int ekf_shard_get_info(ekf_filter* f, ekf_shard_info* out);
 /* ekf_update with z (2 M scalars) resident in device memory and the measured list on the host. */

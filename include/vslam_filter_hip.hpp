@@ -112,6 +112,23 @@ class VSlamFilterHip {
     return t;
   }
 
+  // the same table in the reference's own layout (rows by Patch::real_index, the patches archived at removal
+  // included): `rows` receives the row count; what `f_points << slam.getPointsFeatures()` streams
+  std::vector<float> getPointsTable(int* rows = nullptr) {
+    int r = 0;
+    check(ekf_export_points_table(h_, nullptr, 0, &r));
+    std::vector<float> t(12 * (size_t)r);
+    if (r) check(ekf_export_points_table(h_, t.data(), r, &r));
+    if (rows) *rows = r;
+    return t;
+  }
+  // Patch::real_index / Patch::n_find per live feature
+  void featureIds(std::vector<int>& real_index, std::vector<int>& n_find) {
+    real_index.assign((size_t)numOfFeatures(), 0);
+    n_find.assign((size_t)numOfFeatures(), 0);
+    check(ekf_get_feature_ids(h_, real_index.data(), n_find.data()));
+  }
+
   std::vector<float> getState() {              // VectorXf(14), vR.cpp:135-140
     std::vector<float> s(STATE_DIM);
     check(ekf_get_state(h_, s.data(), 0, STATE_DIM));

@@ -75,26 +75,27 @@ int main() {
         eL += (l - L[i * 128 + j]) * (l - L[i * 128 + j]); nL += L[i * 128 + j] * L[i * 128 + j];
         eD += (d - Li[i * 128 + j]) * (d - Li[i * 128 + j]); nD += Li[i * 128 + j] * Li[i * 128 + j];
       }
+      if (real16 == 8 && which == 0) {      // stamps of THIS launch (every phase on): wave 0 of the workgroup
+        unsigned long long st[64];
+        hipMemcpyFromSymbol(st, HIP_SYMBOL(ekf::ekf_diag_stamps), sizeof(st));
+        for (int b = 0; b < 7; ++b)
+          printf("block %d (wave 0, cycles): own update + factor of block %d: %llu  then waiting for the helper waves' tiles: %llu  panel + barriers: %llu\n", b, b + 1,
+                 st[8 + 4 * b + 2] - st[8 + 4 * b + 1], st[8 + 4 * b + 3] - st[8 + 4 * b + 2],
+                 b < 6 ? st[8 + 4 * (b + 1)] - st[8 + 4 * b + 3] : 0ull /* no stamp after the last block */);
+        printf("diag_factor16 (block 1, wave 0) cycles: prologue incl. the block's own rank-16 update %llu  16 columns %llu  epilogue %llu\n", st[1] - st[0], st[2] - st[1], st[3] - st[2]);
+      }
       printf("real16=%d %-22s rel|L - L64| %.2e  rel|Linv - Linv64| %.2e  status %d\n", real16,
-             which ? "k_chol_diag32" : "k_chol_diag_packed", std::sqrt(eL / nL), std::sqrt(eD / nD), st[0]);
+             "k_chol_diag_packed", std::sqrt(eL / nL), std::sqrt(eD / nD), st[0]);
     }
     if (real16 == 8) {
       printf("k_chol_diag_packed  event pair %.2f us   back to back %.2f us\n",
              run([&] { k_chol_diag_packed<><<<1, 1024>>>(dA, ld, dD, dst, 8); }, dA, dA0, ld, 50),
              run_b2b([&] { k_chol_diag_packed<><<<1, 1024>>>(dA0, ld, dD, dst, 8); }, 200));
-      printf("diag16 masks (b2b us): none %.2f  S1 %.2f  S2 %.2f  S3 %.2f\n",
+      printf("phases alone, back to back (us; the harness build carries s_memtime stamps + waits: ~2 us): none %.2f  factor only %.2f  panel only %.2f  tile updates only %.2f\n",
              run_b2b([&] { k_chol_diag_packed<0><<<1, 1024>>>(dA0, ld, dD, dst, 8); }, 200),
              run_b2b([&] { k_chol_diag_packed<1><<<1, 1024>>>(dA0, ld, dD, dst, 8); }, 200),
              run_b2b([&] { k_chol_diag_packed<2><<<1, 1024>>>(dA0, ld, dD, dst, 8); }, 200),
              run_b2b([&] { k_chol_diag_packed<4><<<1, 1024>>>(dA0, ld, dD, dst, 8); }, 200));
-    }
-    if (real16 == 8) {
-      unsigned long long st[64];
-      hipMemcpyFromSymbol(st, HIP_SYMBOL(ekf::ekf_diag_stamps), sizeof(st));
-      for (int b = 0; b < 7; ++b)
-        printf("block %d (wave 0, cycles): urgent tile %llu  factor16 of the next block %llu  wait for the other waves %llu  panel + barrier %llu\n", b, st[8 + 4 * b + 1] - st[8 + 4 * b],
-               st[8 + 4 * b + 2] - st[8 + 4 * b + 1], st[8 + 4 * b + 3] - st[8 + 4 * b + 2], st[8 + 4 * (b + 1)] - st[8 + 4 * b + 3]);
-      printf("diag_factor16 (block 1, wave 0) cycles: prologue %llu  16 columns %llu  epilogue %llu\n", st[1] - st[0], st[2] - st[1], st[3] - st[2]);
     }
     hipFree(dA); hipFree(dA0); hipFree(dD); hipFree(dst);
   }
