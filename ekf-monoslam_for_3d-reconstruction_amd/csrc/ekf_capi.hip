@@ -209,6 +209,7 @@ struct Filter : FilterBase {
   float* d_score = nullptr;
   int* d_keep = nullptr;
   int opt_panel_direct = 1;                             // EKF_PANEL_DIRECT=0: panel through the general tile GEMM
+  int opt_fused = 1;                                    // EKF_OPT_FUSED_LAUNCHES: k_predict_fused, k_solve_state_oneblock, k_update_oneblock_small
   int opt_fuse_wu = 1;                                  // EKF_FUSE_WU: 0 never, 1 every overlapped chunk but the one before the last, 2 every overlapped chunk
   int env_chunks[8] = {}, env_nchunks = 0;               // EKF_CHUNKS="5,10,14,16": tuning knob (block steps)
   int opt_pipeline = -1;                                 // -1 auto: on when the chain has >= 8 block steps
@@ -360,8 +361,8 @@ struct Filter : FilterBase {
     HIPCHK(hipMalloc(&d_Dinv, (size_t)(ldy / 64) * 128 * 128 * sizeof(T)));
     HIPCHK(hipMalloc(&d_z, (size_t)ldy * sizeof(T)));
     HIPCHK(hipMalloc(&d_midx, cn * sizeof(int)));
-    HIPCHK(hipMalloc(&d_status, 8 * sizeof(int)));          // [0] pivot <= 0, [1] bad device index list; [4..7] scratch of ekf_check_invariants
-    HIPCHK(hipMemsetAsync(d_status, 0, 8 * sizeof(int), stream));
+    HIPCHK(hipMalloc(&d_status, 16 * sizeof(int)));         // [0] pivot <= 0, [1] bad device index list, [3] a bounded device-side wait gave up; [4..7] scratch of ekf_check_invariants; [8] arrival gate of k_predict_fused
+    HIPCHK(hipMemsetAsync(d_status, 0, 16 * sizeof(int), stream));
     HIPCHK(hipMalloc(&d_tmp, 64 * sizeof(T)));
     HIPCHK(hipMalloc(&d_counters, kQueueCounters * sizeof(int)));
     HIPCHK(hipMemset(d_counters, 0, kQueueCounters * sizeof(int)));
@@ -395,6 +396,7 @@ struct Filter : FilterBase {
         HIPCHK(hipStreamCreateWithFlags(&stream_c, hipStreamNonBlocking));
       }
       if (const char* e = getenv("EKF_FUSE_WU")) opt_fuse_wu = atoi(e);
+      if (const char* e = getenv("EKF_FUSED_LAUNCHES")) opt_fused = atoi(e) ? 1 : 0;   // = EKF_OPT_FUSED_LAUNCHES, for A/B runs
       if (const char* e = getenv("EKF_PANEL_DIRECT")) opt_panel_direct = atoi(e);
       if (const char* e = getenv("EKF_SPLIT_TAIL")) opt_split_tail = atoi(e);
       if (const char* e = getenv("EKF_CHUNKS")) {           // tuning knob: chunk ends in block steps
@@ -447,8 +449,9 @@ struct Filter : FilterBase {
     int st[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(st, d_status, sizeof(st), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
-    if (st[0] || st[1]) {
+    if (st[0] || st[1] || st[3]) {
       HIPCHK(hipMemsetAsync(d_status, 0, 4 * sizeof(int), stream));
+      if (st[3]) FAIL(EKF_ERR_DEVICE, "a bounded device-side wait gave up (fused launch)");
       if (st[1])
         FAIL(EKF_ERR_ARG, "ekf_update_device: a device-resident index is outside [0, N) or the list is not strictly "
                           "ascending (indices were clamped; the state is not meaningful)");
@@ -476,6 +479,7 @@ struct Filter : FilterBase {
       case EKF_OPT_PIPELINE: opt_pipeline = (v < 0) ? -1 : v; return EKF_OK;
       case EKF_OPT_SPLIT_BF16: opt_split_bf16 = v ? 1 : 0; return EKF_OK;
       case EKF_OPT_FEATURE_NOISE: opt_feature_noise = (v > 0) ? 1e-12 * v : 0.0; return EKF_OK;
+      case EKF_OPT_FUSED_LAUNCHES: opt_fused = v ? 1 : 0; return EKF_OK;
       default: FAIL(EKF_ERR_ARG, "unknown option");
     }
   }
@@ -799,6 +803,22 @@ struct Filter : FilterBase {
     const T* r = static_cast<const T*>(rc_);
     for (int i = 0; i < 3; ++i) { a.t_ctl[i] = t ? double(t[i]) : 0.0; a.r_ctl[i] = r ? double(r[i]) : 0.0; }
     for (int i = 0; i < 6; ++i) a.vdiag[i] = vcontrol ? vmax[i] : double(T(vmax[i]) * T(2));   // vR.cpp:202
+    if (opt_fused && !opt_streaming && !(opt_feature_noise > 0.0) && N > 0 && !prof_on(KID_PREDICT_CAMERA) &&
+        !prof_on(KID_PROPAGATE_STRIPS) && !prof_on(KID_MEASURE)) {
+      // camera step, strip congruence and the per-feature h / H as ONE launch (k_predict_fused): same arithmetic,
+      // two launches less per frame
+      int rc = sync_layout();
+      if (rc) return rc;
+      const int nstrip = (2 * n + 255) / 256;
+      k_predict_fused<T><<<nstrip + (N + 255) / 256, 256, 0, stream>>>(mu(), d_scr, a, S(), ld, n, nstrip, d_pos, d_coding, N,
+                                                                      cam, d_h, d_Hc, d_Hf, d_flags, d_status + 8, d_status);
+      HIPCHK(hipGetLastError());
+      have_motion = true;
+      have_update = false;
+      have_meas = true;
+      have_sd = false;
+      return launch_blur();
+    }
     {
       Scope sc(this, KID_PREDICT_CAMERA);
       k_predict_camera<T><<<1, 64, 0, stream>>>(mu(), d_scr, a);
@@ -1062,12 +1082,12 @@ struct Filter : FilterBase {
         constexpr int RB = 4;
         dim3 grid((m_pad / 2 + 255) / 256, (n + RB - 1) / RB + extra);
         k_sigma_ht<T, RB><<<grid, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, ip, M, plane, d_W, ldy,
-                                                  m_pad, 0, n, N, zq, d_h, mu(), nuq, d_counters, d_status);
+                                                  m_pad, 0, n, N, zq, d_h, mu(), nuq, d_counters, d_status, d_scr + SCR_QOLD);
       } else {
         constexpr int RB = 32;
         dim3 grid((m_pad / 2 + 255) / 256, (n + RB - 1) / RB + extra);
         k_sigma_ht<T, RB><<<grid, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, ip, M, plane, d_W, ldy,
-                                                  m_pad, 0, n, N, zq, d_h, mu(), nuq, d_counters, d_status);
+                                                  m_pad, 0, n, N, zq, d_h, mu(), nuq, d_counters, d_status, d_scr + SCR_QOLD);
       }
     }
     {
@@ -1094,7 +1114,7 @@ struct Filter : FilterBase {
 
   // Block steps [step0, step1) of the serial chain of chunk [c0, c1) on stream sc_: diagonal factor, panel (rows
   // below the block + the chunk's identity-strip rows), trailing update (strip tiles stop at c1).
-  void chain_steps(int step0, int step1, int c0, int c1, int m, int m_pad, hipStream_t sc_) {
+  void chain_steps(int step0, int step1, int c0, int c1, int m, int m_pad, hipStream_t sc_, bool skip_panel = false) {
     const int nb = NB();
     T* Y = d_Y;
     for (int step = step0; step < step1; ++step) {
@@ -1121,7 +1141,7 @@ struct Filter : FilterBase {
       // (Z rows c0..r0 of this chunk): contiguous, m_pad - c0 of them starting at row r0
       const int r0 = j + nb;
       const int vrows = m_pad - c0;
-      {
+      if (!skip_panel) {
         Scope sc(this, KID_CHOL_PANEL, sc_);                 // P = Y[r0.., j:j+nb] * Linv_jj^T, in place
         T* P = Y + (size_t)r0 * ldy + j;
         launch_panel(P, Dj, vrows, sc_);
@@ -1206,13 +1226,20 @@ struct Filter : FilterBase {
     rc = ensure_tilemap(npad_live / tile, ntr, ntc);
     if (rc) return rc;
 
+    // One diagonal block (2 M + 3 <= 128, the reference's operating point): the chunk inverse is the transposed
+    // Linv of the diagonal factor, so the panel launch, the solve and the state update are ONE launch
+    // (k_solve_state_oneblock); the step is launch-bound there.
+    bool oneblock = false, allinone = false;
+    if constexpr (kIsF32)
+      oneblock = opt_fused && opt_mfma && nchunks == 1 && m_pad == 128 && nb == 128 && !prof_on(KID_SOLVE) &&
+                 !prof_on(KID_STATE_UPDATE) && !prof_on(KID_CHOL_PANEL);
     int step = 0;
     bool b_inflight = false;
     for (int gi = 0; gi < nchunks; ++gi) {
       const int c0 = step * nb, c1 = cend[gi] * nb;
       // chunk 0 has the chip to itself; later chunks run beside the tile GEMMs of stream_b, on the reserved CUs
       hipStream_t sc_ = stream;
-      chain_steps(step, cend[gi], c0, c1, m, m_pad, sc_);
+      chain_steps(step, cend[gi], c0, c1, m, m_pad, sc_, oneblock);
       step = cend[gi];
       const int width = c1 - c0;
       // the last chunk has nothing left to overlap with: it runs on the main stream, on every CU
@@ -1225,7 +1252,19 @@ struct Filter : FilterBase {
         HIPCHK(hipEventRecord(ev_chain[gi], sc_));
         HIPCHK(hipStreamWaitEvent(stream_b, ev_chain[gi], 0));
       }
-      {
+      if (oneblock) {
+        if constexpr (kIsF32) {
+          const int nrb = npad_live / 64, nt64 = nrb * (nrb + 1) / 2;
+          // small map: downdate and normalisation congruence in the same launch, one 64 x 64 tile of Sigma per workgroup
+          allinone = nt64 <= num_cus && !opt_split_bf16 && !prof_on(KID_DOWNDATE) && !prof_on(KID_NORMALIZE);
+          if (allinone)
+            k_update_oneblock_small<<<nt64 + 1, 256, 0, ss>>>(d_W, ldy, d_Dinv, d_V, ldy, npad_live, mu(), n, d_scr + SCR_QOLD,
+                                                             d_scr + SCR_QN, Zs, ldy, S(), ld, nt64);
+          else
+            k_solve_state_oneblock<<<nrb + 1, 256, 0, ss>>>(d_W, ldy, d_Dinv, d_V, ldy, npad_live, mu(), n, d_scr + SCR_QN, Zs,
+                                                           ldy);
+        }
+      } else {
         Scope sc(this, KID_SOLVE, ss);                    // column tiles of the chunk, heaviest first
         const int wt = width / tile;
         const int slots = 2 * (overlap ? num_cus - reserved_cus : num_cus);
@@ -1311,7 +1350,7 @@ struct Filter : FilterBase {
           k_gemm_mfma<ROLE_DOWNDATE, false><<<std::min(g.ntiles, wgs), 256, 0, ss>>>(g);
           HIPCHK(hipEventRecord(ev_wu, stream_b));
         }
-      } else if (!split_done) {
+      } else if (!split_done && !allinone) {
         Scope sc(this, KID_DOWNDATE, ss);                 // Sigma -= V_g V_g^T (lower tiles + mirror)
         if (sc.on) prof_work[KID_DOWNDATE] += double(n) * n * (std::min(c1, m) - std::min(c0, m));   // symmetric half, 2 flop per MAC
         if (kIsF32 && opt_mfma && tri_count < num_cus)    // small map: 64 x 64 tiles, or most of the chip idles
@@ -1334,11 +1373,11 @@ struct Filter : FilterBase {
     for (int g = 0; g < nchunks; ++g) last_cend[g] = cend[g];
     const T* V = d_V;
     const T* yv = d_V + (size_t)npad_live * ldy;
-    if (nchunks == 1) {
+    if (nchunks == 1 && !oneblock) {
       Scope sc(this, KID_STATE_UPDATE);             // mu += V y, then the quaternion normalisation (same launch)
       k_state_update<T><<<(n + 7) / 8, 512, 0, stream>>>(mu(), V, ldy, n, yv, m_pad, d_scr + SCR_QN);
     }
-    {
+    if (!allinone) {
       Scope sc(this, KID_NORMALIZE);
       k_strip_congruence<T, 4><<<(2 * n + 255) / 256, 256, 0, stream>>>(S(), ld, n, 3, d_scr + SCR_QN,
                                                                        static_cast<const T*>(nullptr));

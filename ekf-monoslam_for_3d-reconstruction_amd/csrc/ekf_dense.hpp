@@ -65,10 +65,12 @@ __global__ void k_sigma_ht(const T* __restrict__ S, int ld, int n,
                            int nfeat,
                            const T* __restrict__ z = nullptr, const T* __restrict__ h = nullptr,
                            const T* __restrict__ mu = nullptr, T* __restrict__ nu = nullptr,
-                           int* __restrict__ counters = nullptr, int* __restrict__ status = nullptr) {
+                           int* __restrict__ counters = nullptr, int* __restrict__ status = nullptr,
+                           T* __restrict__ q_old = nullptr) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;    // measurement slot
   const int nslots = m_pad / 2;
   if (nu != nullptr && blockIdx.y == gridDim.y - 1) {
+    if (q_old && k < 4) q_old[k] = mu[3 + k];             // the quaternion before this update (k_update_oneblock_small)
     // one more slab of workgroups than the rows need: the innovation nu = z - h (k_innovation folded into this
     // launch: one launch less in front of the chain) and the reset of the work-queue heads of this update
     if (counters)
@@ -1290,6 +1292,345 @@ __global__ void __launch_bounds__(256, 2) k_panel_direct(float* __restrict__ P, 
   }
   __syncthreads();
   if (live) column_tiles(4);
+}
+
+// ---------------------------------------------------------------------------------------
+// One-block update (f32, the innovation fits one 128-column block: 2 M + 3 <= 128, the reference's operating point).
+// With a single diagonal block the chunk inverse IS the transposed Linv k_chol_diag_packed leaves in Dinv, so the
+// panel step is not needed and
+//     V = [W; nu^T] Linv^T   (the k_panel_direct product out of place; row `rows` of W is nu^T, of V then y^T = (Linv nu)^T)
+//     mu += V y              (y = Linv nu formed by every workgroup for itself from the staged Linv: 8 k MACs)
+// The pieces (one workgroup of 256 lanes; one wave = 16 rows x 128 columns, v_mfma_f32_16x16x4_f32, column tile ct
+// needs k < 16 (ct + 1)):
+// ---------------------------------------------------------------------------------------
+namespace oneblock {
+constexpr int NB = 128, PITCH = 132;
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// Linv (128 x 128, row-major) -> LDS rows of pitch 132; nu -> snu.  The caller synchronises.
+__device__ __forceinline__ void stage(const float* __restrict__ Dinv, const float* __restrict__ nu, float* sl, float* snu, int tid) {
+  f4 v[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    const int q = tid + 256 * p;                   // row q / 32, columns 4 (q % 32) ..
+    v[p] = *reinterpret_cast<const f4*>(Dinv + (size_t)(q >> 5) * NB + 4 * (q & 31));
+  }
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    const int q = tid + 256 * p;
+    *reinterpret_cast<f4*>(sl + (q >> 5) * PITCH + 4 * (q & 31)) = v[p];
+  }
+  if (tid < NB) snu[tid] = nu[tid];
+}
+
+// y = Linv nu: wave w takes rows 32 w .. 32 w + 31, lane = column (two sweeps), butterfly sum.  The same instructions
+// in every workgroup: the same bits.
+__device__ __forceinline__ void form_y(const float* sl, const float* snu, float* sy, int wave, int lane) {
+  for (int i = 0; i < 32; ++i) {
+    const int r = 32 * wave + i;
+    float acc = sl[r * PITCH + lane] * snu[lane];
+    acc = __builtin_fmaf(sl[r * PITCH + 64 + lane], snu[64 + lane], acc);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) sy[r] = acc;
+  }
+}
+
+// The wave's 16 rows [row0, row0 + 16) of V = W Linv^T; out(ct, acc): acc[e] = V[row0 + 4 lq + e][16 ct + lr].
+template <typename Out>
+__device__ __forceinline__ void v_rows(const float* __restrict__ W, int ldw, int row0, const float* sl, int lane, Out out) {
+  const int lr = lane & 15, lq = lane >> 4;
+  f4 fa[8];
+  const float* Wrow = W + (size_t)(row0 + lr) * ldw;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) fa[u] = *reinterpret_cast<const f4*>(Wrow + 16 * u + 4 * lq);
+#pragma unroll
+  for (int ct = 0; ct < 8; ++ct) {
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* bl = sl + (16 * ct + lr) * PITCH + 4 * lq;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (u <= ct) {
+        const f4 fb = *reinterpret_cast<const f4*>(bl + 16 * u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][e], fb[e], acc, 0, 0, 0);
+      }
+    }
+    out(ct, acc);
+  }
+}
+
+// Quaternion normalisation of q (4): q <- q / |q|, Qn = (|q|^2 I - q q^T) / |q|^3 (vR.cpp:1625-1642)
+__device__ __forceinline__ void normalise(float* q, float* Qn) {
+  const float nn = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  const float norma = t_sqrt(nn);
+  const float inv3 = 1.f / (norma * norma * norma);
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) Qn[i * 4 + j] = ((i == j ? norma * norma : 0.f) - q[i] * q[j]) * inv3;
+  for (int i = 0; i < 4; ++i) q[i] = q[i] / norma;
+}
+}  // namespace oneblock
+
+// Gain solve + state update as ONE launch (any map size; the downdate and the normalisation congruence follow as
+// their own launches).  Workgroup b = rows 64 b .. 64 b + 63 of [W; nu^T] (b = rows / 64 holds the nu row and also
+// writes the strip Zs = Linv^T the general path's panel launch would have left: ekf_get_gain and the 1-point RANSAC
+// read it); workgroup 0 holds the quaternion rows: it normalises them and leaves Qn at scr_qn, as k_state_update does.
+__global__ void __launch_bounds__(256, 2)
+k_solve_state_oneblock(const float* __restrict__ W, int ldw, const float* __restrict__ Dinv, float* __restrict__ V, int ldv,
+                       int rows, float* __restrict__ mu, int n, float* __restrict__ scr_qn, float* __restrict__ Zs, int ldz) {
+  using namespace oneblock;
+  __shared__ float sl[NB * PITCH];
+  __shared__ float snu[NB];
+  __shared__ float sy[NB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int row0 = blockIdx.x * 64 + wave * 16;
+  stage(Dinv, W + (size_t)rows * ldw, sl, snu, tid);
+  __syncthreads();
+  form_y(sl, snu, sy, wave, lane);
+  __syncthreads();
+  float part[4] = {0.f, 0.f, 0.f, 0.f};
+  v_rows(W, ldw, row0, sl, lane, [&](int ct, const f4& acc) {
+    const float yc = sy[16 * ct + lr];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      V[(size_t)(row0 + 4 * lq + e) * ldv + 16 * ct + lr] = acc[e];
+      part[e] = __builtin_fmaf(acc[e], yc, part[e]);
+    }
+  });
+#pragma unroll
+  for (int off = 1; off < 16; off <<= 1)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[e] += __shfl_xor(part[e], off, 64);
+  if (lr == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = row0 + 4 * lq + e;
+      if (r < n) mu[r] += part[e];
+    }
+  }
+  if ((int)blockIdx.x == rows / 64) {
+    for (int q = tid; q < NB * NB; q += 256) {
+      const int k = q >> 7, c = q & 127;
+      Zs[(size_t)k * ldz + c] = sl[c * PITCH + k];
+    }
+  }
+  if (blockIdx.x == 0) {
+    __threadfence_block();
+    __syncthreads();                               // rows 3..6 are written (this workgroup holds rows 0..63)
+    if (tid == 0) {
+      float q[4] = {mu[3], mu[4], mu[5], mu[6]}, Qn[16];
+      normalise(q, Qn);
+      for (int i = 0; i < 4; ++i) mu[3 + i] = q[i];
+      for (int i = 0; i < 16; ++i) scr_qn[i] = Qn[i];
+    }
+  }
+}
+
+template <typename T, int K>
+__device__ __forceinline__ void strip_congruence_body(T* __restrict__ S, int ld, int n, int o, const T* sJ, const T* Qs,
+                                                      T* sC, T* sA, int bid, int tid, int nthreads);
+
+// Small maps (every 64 x 64 lower tile of Sigma gets its own workgroup, all resident at once): the WHOLE rest of the
+// update after the diagonal factor as one launch, with no hand-over between workgroups.  Workgroup t = tile (i, j),
+// j <= i, forms the row blocks V_i and V_j it needs for itself (2 x 2 MFLOP; all tiles run side by side), then
+//     Sigma_ij -= V_i V_j^T                         (v_mfma_f32_32x32x2_f32 from LDS, K = 128)
+// The tiles (i, 0) own the rest of the state update for rows 64 i ..: they store V_i, add V_i y to mu, and -- the
+// quaternion rows / columns 3..6 live in block 0 -- apply the normalisation congruence Sigma <- Jn Sigma Jn^T
+// (k_strip_congruence<4>'s formulas) to their tile before it is stored: each forms the updated quaternion
+// q' = q_old + V[3:7] y with the same instructions (q_old: the quaternion before the update, left at q_old by
+// k_sigma_ht's nu slab, because tile (0, 0) overwrites mu[3:7] while others may not have started), hence the same Qn.
+// Tile (0, 0) stores its lower half and mirrors it; the other tiles store the tile and its mirror: Sigma stays exactly
+// symmetric.  One more workgroup (t = ntiles) holds the nu row: y^T into V, and the strip Zs = Linv^T.
+__global__ void __launch_bounds__(256, 1)
+k_update_oneblock_small(const float* __restrict__ W, int ldw, const float* __restrict__ Dinv, float* __restrict__ V, int ldv,
+                        int rows, float* __restrict__ mu, int n, const float* __restrict__ q_old, float* __restrict__ scr_qn,
+                        float* __restrict__ Zs, int ldz, float* __restrict__ S, int lds_, int ntiles) {
+  using namespace oneblock;
+  constexpr int TP = 65;                           // pitch of the 64 x 64 tile image
+  __shared__ float sl[NB * PITCH];                 // Linv; afterwards the tile image (64 x 65)
+  __shared__ float sVi[64 * PITCH];
+  __shared__ float sVj[64 * PITCH];
+  __shared__ float snu[NB];
+  __shared__ float sy[NB];
+  __shared__ float sq[4], sJ[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  stage(Dinv, W + (size_t)rows * ldw, sl, snu, tid);
+  __syncthreads();
+  form_y(sl, snu, sy, wave, lane);
+  __syncthreads();
+  if ((int)blockIdx.x == ntiles) {                 // the nu row: y^T = nu^T Linv^T through the same product, and the strip
+    const int row0 = rows + wave * 16;
+    v_rows(W, ldw, row0, sl, lane, [&](int ct, const f4& acc) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) V[(size_t)(row0 + 4 * lq + e) * ldv + 16 * ct + lr] = acc[e];
+    });
+    for (int q = tid; q < NB * NB; q += 256) {
+      const int k = q >> 7, c = q & 127;
+      Zs[(size_t)k * ldz + c] = sl[c * PITCH + k];
+    }
+    return;
+  }
+  int i = 0;
+  while ((i + 1) * (i + 2) / 2 <= (int)blockIdx.x) ++i;       // tile t -> (i, j), row-major over the lower triangle
+  const int j = blockIdx.x - i * (i + 1) / 2;
+  const bool owner = (j == 0);
+  {
+    const int row0 = 64 * i + wave * 16;
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+    v_rows(W, ldw, row0, sl, lane, [&](int ct, const f4& acc) {
+      const float yc = sy[16 * ct + lr];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sVi[(wave * 16 + 4 * lq + e) * PITCH + 16 * ct + lr] = acc[e];
+        if (owner) {
+          V[(size_t)(row0 + 4 * lq + e) * ldv + 16 * ct + lr] = acc[e];
+          part[e] = __builtin_fmaf(acc[e], yc, part[e]);
+        }
+      }
+    });
+    if (owner) {
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[e] += __shfl_xor(part[e], off, 64);
+      if (lr == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = row0 + 4 * lq + e;
+          if (r < n && !(r >= 3 && r < 7)) mu[r] += part[e];          // the quaternion rows: below, from q'
+        }
+      }
+    }
+  }
+  const float* vj = sVi;
+  if (j != i) {
+    const int row0 = 64 * j + wave * 16;
+    v_rows(W, ldw, row0, sl, lane, [&](int ct, const f4& acc) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sVj[(wave * 16 + 4 * lq + e) * PITCH + 16 * ct + lr] = acc[e];
+    });
+    vj = sVj;
+  }
+  __syncthreads();                                 // V_i, V_j complete; nobody reads Linv any more
+  if (owner && wave == 0) {
+    // q' = q_old + V[3:7] y (rows 3..6 of block j = 0), lane = column (two sweeps), butterfly sum
+    for (int a = 0; a < 4; ++a) {
+      float acc = vj[(3 + a) * PITCH + lane] * sy[lane];
+      acc = __builtin_fmaf(vj[(3 + a) * PITCH + 64 + lane], sy[64 + lane], acc);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+      if (lane == 0) sq[a] = q_old[a] + acc;
+    }
+    if (lane == 0) {
+      float q[4] = {sq[0], sq[1], sq[2], sq[3]}, Qn[16];
+      normalise(q, Qn);
+      for (int k = 0; k < 16; ++k) sJ[k] = Qn[k];
+      if (i == 0) {
+        for (int k = 0; k < 4; ++k) mu[3 + k] = q[k];
+        for (int k = 0; k < 16; ++k) scr_qn[k] = Qn[k];
+      }
+    }
+  }
+  const int wr = wave >> 1, wc = wave & 1, h = lane >> 5, l31 = lane & 31;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  {
+    const float* ap = sVi + (32 * wr + l31) * PITCH + 4 * h;
+    const float* bp = vj + (32 * wc + l31) * PITCH + 4 * h;
+#pragma unroll
+    for (int s8 = 0; s8 < 16; ++s8) {              // lane half h of MFMA e multiplies k = 8 s8 + 4 h + e on both operands
+      const f4 fa = *reinterpret_cast<const f4*>(ap + 8 * s8);
+      const f4 fb = *reinterpret_cast<const f4*>(bp + 8 * s8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc, 0, 0, 0);
+    }
+  }
+  // acc reg e of lane -> row (e & 3) + 8 (e >> 2) + 4 h, column l31 of the wave's 32 x 32 block
+  const int tc = 32 * wc + l31;
+  if (!owner) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int tr = 32 * wr + (e & 3) + 8 * (e >> 2) + 4 * h;
+      const size_t gr = 64 * i + tr, gc = 64 * j + tc;
+      if (gr >= gc) {                              // a diagonal tile: its lower half, mirrored (the upper lanes must not touch it)
+        const float v = S[gr * lds_ + gc] - acc[e];
+        S[gr * lds_ + gc] = v;
+        S[gc * lds_ + gr] = v;
+      }
+    }
+    return;
+  }
+  // tiles (i, 0): the downdated tile through LDS, the normalisation congruence on columns 3..6 (and, tile (0, 0),
+  // rows 3..6 and the corner), then the tile and its mirror
+  float* sT = sl;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int tr = 32 * wr + (e & 3) + 8 * (e >> 2) + 4 * h;
+    sT[tr * TP + tc] = S[(size_t)(64 * i + tr) * lds_ + tc] - acc[e];
+  }
+  __syncthreads();                                 // (also: sJ is there)
+  if (i == 0) {
+    // the lower half is what counts: complete the image symmetrically first, so that rows and columns read the same values
+    for (int q = tid; q < 64 * 64; q += 256) {
+      const int r = q >> 6, c = q & 63;
+      if (c > r) sT[r * TP + c] = sT[c * TP + r];
+    }
+    __syncthreads();
+  }
+  if (tid < 64) {                                  // column strip: row r, columns 3..6 (rows outside the block)
+    const int r = tid;
+    if (i > 0 || r < 3 || r >= 7) {
+      float x[4], yv[4];
+      for (int k = 0; k < 4; ++k) x[k] = sT[r * TP + 3 + k];
+      for (int c = 0; c < 4; ++c) {
+        float a = 0.f;
+        for (int k = 0; k < 4; ++k) a = __builtin_fmaf(x[k], sJ[c * 4 + k], a);
+        yv[c] = a;
+      }
+      for (int c = 0; c < 4; ++c) sT[r * TP + 3 + c] = yv[c];
+    }
+  } else if (i == 0 && tid < 128) {                // row strip of tile (0, 0): column c, rows 3..6
+    const int c = tid - 64;
+    if (c < 3 || c >= 7) {
+      float x[4], yv[4];
+      for (int k = 0; k < 4; ++k) x[k] = sT[(3 + k) * TP + c];
+      for (int r = 0; r < 4; ++r) {
+        float a = 0.f;
+        for (int k = 0; k < 4; ++k) a = __builtin_fmaf(sJ[r * 4 + k], x[k], a);
+        yv[r] = a;
+      }
+      for (int r = 0; r < 4; ++r) sT[(3 + r) * TP + c] = yv[r];
+    }
+  } else if (i == 0 && tid == 128) {               // corner: lower half of J C J^T, mirrored
+    float C[16], A[16];
+    for (int k = 0; k < 16; ++k) C[k] = sT[(3 + k / 4) * TP + 3 + k % 4];
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) {
+        float a = 0.f;
+        for (int k = 0; k < 4; ++k) a += sJ[r * 4 + k] * C[k * 4 + c];
+        A[r * 4 + c] = a;
+      }
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c <= r; ++c) {
+        float a = 0.f;
+        for (int k = 0; k < 4; ++k) a += A[r * 4 + k] * sJ[c * 4 + k];
+        sT[(3 + r) * TP + 3 + c] = a;
+        sT[(3 + c) * TP + 3 + r] = a;
+      }
+  }
+  __syncthreads();
+  for (int q = tid; q < 64 * 64; q += 256) {
+    const int r = q >> 6, c = q & 63;
+    if (i == 0) {
+      S[(size_t)r * lds_ + c] = (r >= c) ? sT[r * TP + c] : sT[c * TP + r];
+    } else {
+      S[(size_t)(64 * i + r) * lds_ + c] = sT[r * TP + c];
+      S[(size_t)r * lds_ + 64 * i + c] = sT[c * TP + r];         // the mirror tile (0, i): row r, column 64 i + c
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------

@@ -14,7 +14,7 @@ enum : int {
   SCR_QN = 338,       // 4x4 quaternion-normalisation Jacobian
   SCR_G = 354,        // add-feature: 6x7 d f / d[r,q]
   SCR_C = 396,        // add-feature: 6x6 corner block
-  SCR_JY = 432,       // convert: up to MAX_CONVERT 3x6 Jacobians (dynamic; separate buffer used)
+  SCR_QOLD = 432,     // the quaternion before the update in flight (k_sigma_ht's nu slab -> k_update_oneblock_small)
   SCR_SIZE = 512
 };
 
@@ -28,19 +28,13 @@ struct MotionArgs {
 // ---------------------------------------------------------------------------------------
 // a2 + a3: Ft, Q and the camera state step.  One lane; ~1k flops.   (vR.cpp:1492-1535, 1575-1589)
 // ---------------------------------------------------------------------------------------
+// The one-lane core: sx = camera state (13), sF = Ft in LDS, preset to the identity (nullptr: state step only),
+// xn = the predicted camera state (13).
 template <typename T>
-__global__ void k_predict_camera(T* __restrict__ mu, T* __restrict__ scr, MotionArgs a) {
-  // one workgroup of 64 lanes: lane 0 forms the two non-trivial blocks of Ft, all lanes fill Ft / Q
-  __shared__ T sF[169];
-  __shared__ T sx[13];
-  const int tid = threadIdx.x;
-  if (blockIdx.x != 0) return;
-  if (tid < 13) sx[tid] = mu[tid];
-  for (int i = tid; i < 169; i += blockDim.x) sF[i] = (i / 13 == i % 13) ? T(1) : T(0);
-  __syncthreads();
+__device__ __forceinline__ void camera_step(const T* sx, const MotionArgs& a, T* sF, T* xn) {
   const T dTt = T(a.dT);
-  if (tid == 0) {
-    const T q[4] = {sx[3], sx[4], sx[5], sx[6]};
+  const T q[4] = {sx[3], sx[4], sx[5], sx[6]};
+  if (sF) {
     const T wc[3] = {sx[10] + T(a.r_ctl[0]), sx[11] + T(a.r_ctl[1]), sx[12] + T(a.r_ctl[2])};
     const T hv[3] = {dTt * wc[0], dTt * wc[1], dTt * wc[2]};
     T h[4];
@@ -87,29 +81,51 @@ __global__ void k_predict_camera(T* __restrict__ mu, T* __restrict__ scr, Motion
       }
 #pragma unroll
     for (int i = 0; i < 3; ++i) sF[i * 13 + 7 + i] = dTt;
-    // Predict_State
-    const T v[3] = {sx[7] + T(a.t_ctl[0]), sx[8] + T(a.t_ctl[1]), sx[9] + T(a.t_ctl[2])};
-    const T w[3] = {sx[10] + T(a.r_ctl[0]), sx[11] + T(a.r_ctl[1]), sx[12] + T(a.r_ctl[2])};
-    T dq[4], qn[4];
-    const T wv[3] = {dTt * w[0], dTt * w[1], dTt * w[2]};
-    vec2quat(wv, dq);
-    quat_mul(q, dq, qn);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) mu[i] = sx[i] + dTt * v[i];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) mu[3 + i] = qn[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { mu[7 + i] = v[i]; mu[10 + i] = w[i]; }
   }
-  __syncthreads();
-  // Ft and Q = Ft[:,7:13] diag(V / dT / dT) Ft[:,7:13]^T, one entry per lane-iteration
-  for (int e = tid; e < 169; e += blockDim.x) {
-    const int i = e / 13, j = e % 13;
-    scr[SCR_FT + e] = sF[e];
-    T acc = T(0);
+  // Predict_State
+  const T v[3] = {sx[7] + T(a.t_ctl[0]), sx[8] + T(a.t_ctl[1]), sx[9] + T(a.t_ctl[2])};
+  const T w[3] = {sx[10] + T(a.r_ctl[0]), sx[11] + T(a.r_ctl[1]), sx[12] + T(a.r_ctl[2])};
+  T dq[4], qn[4];
+  const T wv[3] = {dTt * w[0], dTt * w[1], dTt * w[2]};
+  vec2quat(wv, dq);
+  quat_mul(q, dq, qn);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) acc += sF[i * 13 + 7 + k] * (T(a.vdiag[k]) / dTt / dTt) * sF[j * 13 + 7 + k];
-    scr[SCR_Q + e] = acc;
+  for (int i = 0; i < 3; ++i) xn[i] = sx[i] + dTt * v[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xn[3 + i] = qn[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { xn[7 + i] = v[i]; xn[10 + i] = w[i]; }
+}
+
+// Q = Ft[:,7:13] diag(V / dT / dT) Ft[:,7:13]^T, entry e = 13 i + j
+template <typename T>
+__device__ __forceinline__ T process_noise_entry(const T* sF, const MotionArgs& a, int e) {
+  const int i = e / 13, j = e % 13;
+  const T dTt = T(a.dT);
+  T acc = T(0);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) acc += sF[i * 13 + 7 + k] * (T(a.vdiag[k]) / dTt / dTt) * sF[j * 13 + 7 + k];
+  return acc;
+}
+
+template <typename T>
+__global__ void k_predict_camera(T* __restrict__ mu, T* __restrict__ scr, MotionArgs a) {
+  // one workgroup of 64 lanes: lane 0 forms the two non-trivial blocks of Ft, all lanes fill Ft / Q
+  __shared__ T sF[169];
+  __shared__ T sx[13];
+  __shared__ T sxn[13];
+  const int tid = threadIdx.x;
+  if (blockIdx.x != 0) return;
+  if (tid < 13) sx[tid] = mu[tid];
+  for (int i = tid; i < 169; i += blockDim.x) sF[i] = (i / 13 == i % 13) ? T(1) : T(0);
+  __syncthreads();
+  if (tid == 0) camera_step(sx, a, sF, sxn);
+  __syncthreads();
+  if (tid < 13) mu[tid] = sxn[tid];
+  // Ft and Q, one entry per lane-iteration
+  for (int e = tid; e < 169; e += blockDim.x) {
+    scr[SCR_FT + e] = sF[e];
+    scr[SCR_Q + e] = process_noise_entry(sF, a, e);
   }
 }
 
@@ -120,13 +136,12 @@ __global__ void k_predict_camera(T* __restrict__ mu, T* __restrict__ scr, Motion
 //   lane t >= n : row (t-n) of the column strip
 //   block 0 additionally owns the KxK corner.
 // ---------------------------------------------------------------------------------------
+// The body for workgroup `bid` of `nthreads` lanes; sJ (K x K) and, for bid 0, Qs (K x K or nullptr) may live in LDS or
+// in global memory; sC / sA: two K x K LDS scratch blocks (used by bid 0 only).
 template <typename T, int K>
-__global__ void k_strip_congruence(T* __restrict__ S, int ld, int n, int o,
-                                   const T* __restrict__ Jm, const T* __restrict__ Qm) {
-  __shared__ T sJ[K * K];
-  for (int i = threadIdx.x; i < K * K; i += blockDim.x) sJ[i] = Jm[i];
-  __syncthreads();
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void strip_congruence_body(T* __restrict__ S, int ld, int n, int o, const T* sJ, const T* Qs,
+                                                      T* sC, T* sA, int bid, int tid, int nthreads) {
+  const int t = bid * nthreads + tid;
   if (t < n) {
     if (t < o || t >= o + K) {             // row strip, column t
       T x[K], y[K];
@@ -159,13 +174,11 @@ __global__ void k_strip_congruence(T* __restrict__ S, int ld, int n, int o,
       for (int c = 0; c < K; ++c) S[(size_t)i * ld + o + c] = y[c];
     }
   }
-  if (blockIdx.x == 0) {                   // corner: J C J^T + Q through LDS
-    __shared__ T sC[K * K];
-    __shared__ T sA[K * K];
-    for (int i = threadIdx.x; i < K * K; i += blockDim.x)
+  if (bid == 0) {                          // corner: J C J^T + Q through LDS
+    for (int i = tid; i < K * K; i += nthreads)
       sC[i] = S[(size_t)(o + i / K) * ld + o + i % K];
     __syncthreads();
-    for (int i = threadIdx.x; i < K * K; i += blockDim.x) {
+    for (int i = tid; i < K * K; i += nthreads) {
       const int r = i / K, c = i % K;
       T acc = T(0);
       for (int k = 0; k < K; ++k) acc += sJ[r * K + k] * sC[k * K + c];
@@ -174,16 +187,27 @@ __global__ void k_strip_congruence(T* __restrict__ S, int ld, int n, int o,
     __syncthreads();
     // lower triangle only, mirrored: (J C) J^T is symmetric in exact arithmetic, not in its rounding -- and the
     // rest of the update keeps Sigma EXACTLY symmetric (the downdate mirrors its lower tiles)
-    for (int i = threadIdx.x; i < K * K; i += blockDim.x) {
+    for (int i = tid; i < K * K; i += nthreads) {
       const int r = i / K, c = i % K;
       if (c > r) continue;
       T acc = T(0);
       for (int k = 0; k < K; ++k) acc += sA[r * K + k] * sJ[c * K + k];
-      if (Qm) acc += Qm[i];
+      if (Qs) acc += Qs[i];
       S[(size_t)(o + r) * ld + o + c] = acc;
       S[(size_t)(o + c) * ld + o + r] = acc;
     }
   }
+}
+
+template <typename T, int K>
+__global__ void k_strip_congruence(T* __restrict__ S, int ld, int n, int o,
+                                   const T* __restrict__ Jm, const T* __restrict__ Qm) {
+  __shared__ T sJ[K * K];
+  __shared__ T sC[K * K];
+  __shared__ T sA[K * K];
+  for (int i = threadIdx.x; i < K * K; i += blockDim.x) sJ[i] = Jm[i];
+  __syncthreads();
+  strip_congruence_body<T, K>(S, ld, n, o, sJ, Qm, sC, sA, blockIdx.x, threadIdx.x, blockDim.x);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -282,6 +306,12 @@ __global__ void k_propagate_streaming(const T* __restrict__ src, T* __restrict__
 // overrides the camera part of mu -- the high-innovation rescue linearises the features of the UPDATED
 // state around the camera pose of the state BEFORE the first update (vR.cpp:1069-1072, 1085).
 template <typename T>
+__device__ __forceinline__ void measure_feature(int i, const T* __restrict__ mu, const int* __restrict__ pos,
+                                                const int* __restrict__ coding, const CamParams& cam,
+                                                T* __restrict__ h_out, T* __restrict__ Hc, T* __restrict__ Hf,
+                                                unsigned char* __restrict__ flags, const T* cam_pose);
+
+template <typename T>
 __global__ void k_measure(const T* __restrict__ mu,
                           const int* __restrict__ pos, const int* __restrict__ coding, int f_begin, int N,
                           CamParams cam,
@@ -295,6 +325,14 @@ __global__ void k_measure(const T* __restrict__ mu,
     i = list[i];
   }
   if (i >= N) return;
+  measure_feature<T>(i, mu, pos, coding, cam, h_out, Hc, Hf, flags, cam_pose);
+}
+
+template <typename T>
+__device__ __forceinline__ void measure_feature(int i, const T* __restrict__ mu, const int* __restrict__ pos,
+                                                const int* __restrict__ coding, const CamParams& cam,
+                                                T* __restrict__ h_out, T* __restrict__ Hc, T* __restrict__ Hf,
+                                                unsigned char* __restrict__ flags, const T* cam_pose) {
   const int p = pos[i];
   const bool xyz = coding[i] != 0;
   const int fs = xyz ? 3 : 6;
@@ -360,6 +398,63 @@ __global__ void k_measure(const T* __restrict__ mu,
   for (int k = 0; k < 14; ++k) Hc[(size_t)i * 14 + k] = hc[k];
   for (int k = 0; k < 12; ++k) Hf[(size_t)i * 12 + k] = hf[k];
   flags[i] = fl;
+}
+
+// ---------------------------------------------------------------------------------------
+// a1 + a2 + a3 + a4 in ONE launch (the in-place propagate; small maps are launch-bound): workgroups [0, nstrip) are
+// the strip congruence of a1, the rest one lane per feature of a4 / a5.  Every workgroup reads the OLD camera state
+// and repeats the one-lane step of a2 / a3 for itself (the same instructions as k_predict_camera: bit-identical); workgroup 0
+// commits the new camera state, Ft and Q once every other workgroup has read the old one (`gate`: one arrival per
+// workgroup; nobody but workgroup 0 waits, so the order in which workgroups become resident does not matter).
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_predict_fused(T* __restrict__ mu, T* __restrict__ scr, MotionArgs a,
+                                                       T* __restrict__ S, int ld, int n, int nstrip,
+                                                       const int* __restrict__ pos, const int* __restrict__ coding, int N,
+                                                       CamParams cam, T* __restrict__ h_out, T* __restrict__ Hc,
+                                                       T* __restrict__ Hf, unsigned char* __restrict__ flags,
+                                                       int* __restrict__ gate, int* __restrict__ status) {
+  __shared__ T sF[169];
+  __shared__ T sQ[169];
+  __shared__ T sC[169];
+  __shared__ T sA[169];
+  __shared__ T sx[13];
+  __shared__ T sxn[13];
+  const int tid = threadIdx.x, bid = blockIdx.x;
+  const bool strip = bid < nstrip;
+  if (tid < 13) sx[tid] = mu[tid];
+  for (int i = tid; i < 169; i += 256) sF[i] = (i / 13 == i % 13) ? T(1) : T(0);
+  __syncthreads();                                   // the old camera state is in LDS: this workgroup is done with mu[0:13]
+  if (tid == 0) {
+    if (bid != 0) __hip_atomic_fetch_add(gate, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    camera_step(sx, a, strip ? sF : static_cast<T*>(nullptr), sxn);
+  }
+  __syncthreads();
+  if (!strip) {
+    const int i = (bid - nstrip) * 256 + tid;
+    if (i < N) measure_feature<T>(i, mu, pos, coding, cam, h_out, Hc, Hf, flags, sxn);
+    return;
+  }
+  if (bid == 0) {
+    for (int e = tid; e < 169; e += 256) {
+      const T qv = process_noise_entry(sF, a, e);
+      sQ[e] = qv;
+      scr[SCR_FT + e] = sF[e];
+      scr[SCR_Q + e] = qv;
+    }
+    __syncthreads();
+  }
+  strip_congruence_body<T, 13>(S, ld, n, 0, sF, sQ, sC, sA, bid, tid, 256);
+  if (bid == 0 && tid == 0) {
+    bool ok = false;
+    for (int spin = 0; spin < (1 << 20) && !ok; ++spin) {
+      ok = __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (int)gridDim.x - 1;
+      if (!ok) __builtin_amdgcn_s_sleep(8);
+    }
+    if (!ok) status[3] = 1;
+    for (int k = 0; k < 13; ++k) mu[k] = sxn[k];
+    __hip_atomic_store(gate, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // 2x2 diagonal block of St per feature: Hrow P Hrow^T + r_pix I with P = Sigma[idx, idx],

@@ -93,7 +93,13 @@ enum ekf_option {
    * noise" of EKF-SLAM practice, for callers who want it.  The fp32 filter does not need it to stay positive: with
    * every feature measured in every frame Sigma stays positive to rounding over every run followed so far (N = 200:
    * 12000 frames, 1000: 3000, 4000: 1200; profiles/r2_drift_after_fix.txt).  Any dtype. */
-  EKF_OPT_FEATURE_NOISE = 5
+  EKF_OPT_FEATURE_NOISE = 5,
+  /* 1 (default): launch-bound sequences go out as fused launches where that changes no result beyond rounding --
+   * camera step + strip congruence + per-feature h / H of ekf_predict as one launch (bit-identical to the three), and,
+   * when the innovation fits one 128-column block (2 M + 3 <= 128: the reference's operating point of <= 35 features),
+   * gain solve + state update as one launch without the panel step (same sums in another order: fp32 rounding).
+   * 0: one launch per kernel (what the per-kernel profile of EKF_OPT_PROFILE = 2 times). */
+  EKF_OPT_FUSED_LAUNCHES = 6
 };
 
 /* Fills `cfg` with the reference defaults (ConfigVSLAM.cpp:27-47, camModel.hpp:22-31). */

@@ -965,3 +965,47 @@ def test_n1000_default_pipeline_matches_fp64_oracle():
                      (k + 1) * 2.5 * TOL[np.float32]["S"])
     pad, asym, big = f.checkInvariants()
     assert pad == 0.0 and asym == 0.0
+
+
+@pytest.mark.parametrize("n_feat", [30, 200])
+def test_fused_launches_match_launch_per_kernel(n_feat):
+    """EKF_OPT_FUSED_LAUNCHES (default on): (a) camera step + strip congruence + per-feature h / H of ekf_predict as ONE
+    launch is bit-identical to the three (every workgroup repeats the same one-lane camera step); (b) with the
+    innovation inside one 128-column block (n_feat = 30: 2 M + 3 = 63) the solve + state update go out as one launch
+    without the panel step -- the same sums in another order: fp32 rounding, and the gain / the strip the general path
+    leaves are there too.  n_feat = 200 (four blocks) only has (a), so the whole run stays bit-identical."""
+    ref, g1 = make_pair(n_feat, np.float32)
+    _, g0 = make_pair(n_feat, np.float32)
+    g0.set_option(6, 0)                                          # one launch per kernel
+    for k in range(3):
+        ref.predict()
+        g1.predict()
+        g0.predict()
+        mu1, S1 = gpu_state(g1)
+        mu0, S0 = gpu_state(g0)
+        p1, p0 = g1.predictions(jacobians=True), g0.predictions(jacobians=True)
+        Ft1, Q1 = g1.motionJacobian()
+        Ft0, Q0 = g0.motionJacobian()
+        if n_feat > 62 or k == 0:                                # same state in: same bits out
+            assert np.array_equal(Ft1, Ft0) and np.array_equal(Q1, Q0)
+            assert np.array_equal(mu1, mu0) and np.array_equal(S1, S0)
+            for a, b in zip(p1, p0):
+                assert np.array_equal(np.asarray(a), np.asarray(b))
+        vis = ref.visible_indices()
+        z = o.synthetic_measurements(ref, vis, seed=500 + k)
+        ref.update(z, vis)
+        g1.update(z, vis)
+        g0.update(z, vis)
+        mu1, S1 = gpu_state(g1)
+        mu0, S0 = gpu_state(g0)
+        if n_feat > 62:
+            assert np.array_equal(mu1, mu0) and np.array_equal(S1, S0)
+        else:
+            assert bound(f"frame {k}: mu fused vs launch-per-kernel", relf(mu1, mu0), 2e-6 * (k + 1))
+            assert bound(f"frame {k}: Sigma fused vs launch-per-kernel", relf(S1, S0), 5e-6 * (k + 1))
+            assert bound(f"frame {k}: gain fused vs launch-per-kernel", relf(g1.getGain(), g0.getGain()), 1e-4 * (k + 1))
+        assert bound(f"frame {k}: mu vs oracle", relf(mu1, ref.mu), TOL[np.float32]["mu"] * 5 * (k + 1))
+        assert bound(f"frame {k}: Sigma vs oracle", relf(S1, ref.Sigma), TOL[np.float32]["S"] * (k + 1))
+        assert np.array_equal(S1, S1.T)
+    g1.synchronize()
+    g0.synchronize()

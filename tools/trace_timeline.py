@@ -5,8 +5,8 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def short(n):
     n = re.sub(r"\(.*", "", n).replace("void ekf::", "").replace("ekf::", "")
     return n[:40]
-# find the last k_predict_camera -> next k_predict_camera window
-idx = [i for i, r in enumerate(rows) if "k_predict_camera" in r["Kernel_Name"]]
+# find the last k_predict_camera / k_predict_fused -> next one window
+idx = [i for i, r in enumerate(rows) if "k_predict_camera" in r["Kernel_Name"] or "k_predict_fused" in r["Kernel_Name"]]
 a, b = idx[-3], idx[-2]
 t0 = int(rows[a]["Start_Timestamp"])
 print("step window %.1f us" % ((int(rows[b]["Start_Timestamp"]) - t0) / 1e3))
