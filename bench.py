@@ -498,6 +498,33 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
                                                 "algorithmic_bytes_per_step": b32}}
         flt3.close()
 
+        if n_feat >= 600:
+            # the reference's own operating point as a map (conf_sim.cfg:20-25: <= 35 features, all of them measured):
+            # N = 32, n = 205, 2 M + 3 <= 128 -- one diagonal block, so the update after the diagonal factor is ONE launch
+            # (k_update_oneblock_small) and the step is 5 launches: launch-latency-bound, reported as such
+            n32 = 32
+            fr32 = 400
+            px32, z32 = synthetic.measurement_stream(cfg, n32, fr32, sigma_px=SIGMA_Z_PX)
+            flt7 = FilterRing(pkg, cfg, n32, px32, z32, fr32)
+            d_z7 = torch.from_numpy(z32.reshape(fr32, -1)).to(dev).contiguous()
+            d_i7 = torch.arange(n32, dtype=torch.int32, device=dev)
+            bpf7 = 2 * n32 * 4
+            run_steps(flt7, d_z7, d_i7, n32, 0, 50, bpf7)
+            flt7.synchronize()
+            t0 = time.perf_counter()
+            run_steps(flt7, d_z7, d_i7, n32, 50, fr32 - 50, bpf7)
+            flt7.synchronize()
+            t1 = time.perf_counter()
+            t7 = (t1 - t0) / (fr32 - 50)
+            mu7 = flt7.at(fr32 - 1).getFullState()
+            result["secondary_N32_map"] = {
+                "what": "a 32-feature map (n = 205), every feature measured in every frame: the reference's operating point",
+                "value": round(1.0 / t7, 1), "unit": "updates/s", "ms_per_step": round(1e3 * t7, 4), "launches_per_step": 5,
+                "roofline": {"bound": "latency", "basis": "5 dependent launches of 5-10 us each (predict, W, S, diagonal factor, "
+                             "fused update); 3 n^2 s = 0.5 MB of traffic per step"},
+                "run_sane": bool(np.all(np.isfinite(mu7)) and abs(np.linalg.norm(mu7[3:7]) - 1) < 1e-4)}
+            flt7.close()
+
         if n_feat < 600:
             # small maps (configs[1], N = 200) are LATENCY-bound: one column chunk, a serial chain of a few block steps and
             # ~20 launches per step; say so with numbers next to the MFMA roofline of the (tiny) downdate

@@ -1215,6 +1215,14 @@ struct Filter : FilterBase {
       tab.end[g] = cend[g] * nb;
       strip_rows = std::max(strip_rows, (cend[g] - (g ? cend[g - 1] : 0)) * nb);
     }
+    // One diagonal block (2 M + 3 <= 128, the reference's operating point): the chunk inverse is the transposed
+    // Linv of the diagonal factor, so the panel launch, the solve and the state update are ONE launch
+    // (k_solve_state_oneblock; small maps: the downdate and the normalisation too, k_update_oneblock_small): the step is
+    // launch-bound there.
+    bool oneblock = false, allinone = false;
+    if constexpr (kIsF32)
+      oneblock = opt_fused && opt_mfma && nchunks == 1 && m_pad == 128 && nb == 128 && !prof_on(KID_SOLVE) &&
+                 !prof_on(KID_STATE_UPDATE) && !prof_on(KID_CHOL_PANEL);
     int rc = build_innovation(M, plane, true, &m, &m_pad, &tab, strip_rows);
     cur_z = nullptr;
     cur_midx = nullptr;
@@ -1226,13 +1234,6 @@ struct Filter : FilterBase {
     rc = ensure_tilemap(npad_live / tile, ntr, ntc);
     if (rc) return rc;
 
-    // One diagonal block (2 M + 3 <= 128, the reference's operating point): the chunk inverse is the transposed
-    // Linv of the diagonal factor, so the panel launch, the solve and the state update are ONE launch
-    // (k_solve_state_oneblock); the step is launch-bound there.
-    bool oneblock = false, allinone = false;
-    if constexpr (kIsF32)
-      oneblock = opt_fused && opt_mfma && nchunks == 1 && m_pad == 128 && nb == 128 && !prof_on(KID_SOLVE) &&
-                 !prof_on(KID_STATE_UPDATE) && !prof_on(KID_CHOL_PANEL);
     int step = 0;
     bool b_inflight = false;
     for (int gi = 0; gi < nchunks; ++gi) {
@@ -1258,7 +1259,7 @@ struct Filter : FilterBase {
           // small map: downdate and normalisation congruence in the same launch, one 64 x 64 tile of Sigma per workgroup
           allinone = nt64 <= num_cus && !opt_split_bf16 && !prof_on(KID_DOWNDATE) && !prof_on(KID_NORMALIZE);
           if (allinone)
-            k_update_oneblock_small<<<nt64 + 1, 256, 0, ss>>>(d_W, ldy, d_Dinv, d_V, ldy, npad_live, mu(), n, d_scr + SCR_QOLD,
+            k_update_oneblock_small<<<nt64 + 1, 512, 0, ss>>>(d_W, ldy, d_Dinv, d_V, ldy, npad_live, mu(), n, d_scr + SCR_QOLD,
                                                              d_scr + SCR_QN, Zs, ldy, S(), ld, nt64);
           else
             k_solve_state_oneblock<<<nrb + 1, 256, 0, ss>>>(d_W, ldy, d_Dinv, d_V, ldy, npad_live, mu(), n, d_scr + SCR_QN, Zs,

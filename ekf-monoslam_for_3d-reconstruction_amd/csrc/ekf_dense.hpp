@@ -1431,18 +1431,21 @@ template <typename T, int K>
 __device__ __forceinline__ void strip_congruence_body(T* __restrict__ S, int ld, int n, int o, const T* sJ, const T* Qs,
                                                       T* sC, T* sA, int bid, int tid, int nthreads);
 
-// Small maps (every 64 x 64 lower tile of Sigma gets its own workgroup, all resident at once): the WHOLE rest of the
+// Small maps (every 64 x 64 lower tile of Sigma gets its own workgroup, all of them side by side): the WHOLE rest of the
 // update after the diagonal factor as one launch, with no hand-over between workgroups.  Workgroup t = tile (i, j),
-// j <= i, forms the row blocks V_i and V_j it needs for itself (2 x 2 MFLOP; all tiles run side by side), then
-//     Sigma_ij -= V_i V_j^T                         (v_mfma_f32_32x32x2_f32 from LDS, K = 128)
-// The tiles (i, 0) own the rest of the state update for rows 64 i ..: they store V_i, add V_i y to mu, and -- the
-// quaternion rows / columns 3..6 live in block 0 -- apply the normalisation congruence Sigma <- Jn Sigma Jn^T
-// (k_strip_congruence<4>'s formulas) to their tile before it is stored: each forms the updated quaternion
-// q' = q_old + V[3:7] y with the same instructions (q_old: the quaternion before the update, left at q_old by
+// j <= i, 8 waves: waves 0..3 form the row block V_i, waves 4..7 V_j (2 x 2 MFLOP per workgroup, all tiles in
+// parallel; the W rows are requested before Linv is staged), then
+//     Sigma_ij -= V_i V_j^T                         (v_mfma_f32_16x16x4_f32 from LDS, K = 128, two 16 x 16 blocks per wave;
+//                                                    the Sigma values are requested before the products)
+// The tiles (i, 0) own the rest of the state update for rows 64 i ..: they store V_i, form y = Linv nu, add V_i y to
+// mu, and -- the quaternion rows / columns 3..6 live in block 0 -- apply the normalisation congruence
+// Sigma <- Jn Sigma Jn^T (k_strip_congruence<4>'s formulas) to their tile before it is stored: each forms the updated
+// quaternion q' = q_old + V[3:7] y with the same instructions (q_old: the quaternion before the update, left there by
 // k_sigma_ht's nu slab, because tile (0, 0) overwrites mu[3:7] while others may not have started), hence the same Qn.
-// Tile (0, 0) stores its lower half and mirrors it; the other tiles store the tile and its mirror: Sigma stays exactly
-// symmetric.  One more workgroup (t = ntiles) holds the nu row: y^T into V, and the strip Zs = Linv^T.
-__global__ void __launch_bounds__(256, 1)
+// Tile (0, 0) stores its lower half and mirrors it; a diagonal tile (i, i) updates its lower half and mirrors it; the
+// others store the tile and its mirror: Sigma stays exactly symmetric.  One more workgroup (t = ntiles) holds the nu
+// row: y^T into V, and the strip Zs = Linv^T.
+__global__ void __launch_bounds__(512, 1)
 k_update_oneblock_small(const float* __restrict__ W, int ldw, const float* __restrict__ Dinv, float* __restrict__ V, int ldv,
                         int rows, float* __restrict__ mu, int n, const float* __restrict__ q_old, float* __restrict__ scr_qn,
                         float* __restrict__ Zs, int ldz, float* __restrict__ S, int lds_, int ntiles) {
@@ -1456,66 +1459,110 @@ k_update_oneblock_small(const float* __restrict__ W, int ldw, const float* __res
   __shared__ float sq[4], sJ[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lq = lane >> 4;
-  stage(Dinv, W + (size_t)rows * ldw, sl, snu, tid);
-  __syncthreads();
-  form_y(sl, snu, sy, wave, lane);
-  __syncthreads();
-  if ((int)blockIdx.x == ntiles) {                 // the nu row: y^T = nu^T Linv^T through the same product, and the strip
-    const int row0 = rows + wave * 16;
-    v_rows(W, ldw, row0, sl, lane, [&](int ct, const f4& acc) {
+  const bool nu_wg = (int)blockIdx.x == ntiles;
+  int i = 0;
+  while ((i + 1) * (i + 2) / 2 <= (int)blockIdx.x) ++i;       // tile t -> (i, j), row-major over the lower triangle
+  const int j = blockIdx.x - i * (i + 1) / 2;
+  const bool owner = !nu_wg && (j == 0);
+  const bool second = wave >= 4;                   // waves 4..7: V_j
+  // this wave's 16 rows of [W; nu^T]
+  const int vrow0 = nu_wg ? rows + (wave & 3) * 16 : 64 * (second ? j : i) + (wave & 3) * 16;
+  const bool v_active = nu_wg ? !second : (!second || j != i);
+  f4 fa[8];
+  if (v_active) {
+    const float* Wrow = W + (size_t)(vrow0 + lr) * ldw;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) V[(size_t)(row0 + 4 * lq + e) * ldv + 16 * ct + lr] = acc[e];
-    });
-    for (int q = tid; q < NB * NB; q += 256) {
+    for (int u = 0; u < 8; ++u) fa[u] = *reinterpret_cast<const f4*>(Wrow + 16 * u + 4 * lq);
+  }
+  {
+    f4 v[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int q = tid + 512 * p;                 // row q / 32, columns 4 (q % 32) ..
+      v[p] = *reinterpret_cast<const f4*>(Dinv + (size_t)(q >> 5) * NB + 4 * (q & 31));
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int q = tid + 512 * p;
+      *reinterpret_cast<f4*>(sl + (q >> 5) * PITCH + 4 * (q & 31)) = v[p];
+    }
+    if (tid < NB) snu[tid] = W[(size_t)rows * ldw + tid];
+  }
+  __syncthreads();
+  if (owner && tid < 2 * NB) {
+    // y = Linv nu: two lanes per row (halves of k), four running sums each: the same instructions in every owner
+    const int r = tid >> 1, k0 = 64 * (tid & 1);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < 64; k += 4) {
+      a0 = __builtin_fmaf(sl[r * PITCH + k0 + k], snu[k0 + k], a0);
+      a1 = __builtin_fmaf(sl[r * PITCH + k0 + k + 1], snu[k0 + k + 1], a1);
+      a2 = __builtin_fmaf(sl[r * PITCH + k0 + k + 2], snu[k0 + k + 2], a2);
+      a3 = __builtin_fmaf(sl[r * PITCH + k0 + k + 3], snu[k0 + k + 3], a3);
+    }
+    float acc = (a0 + a1) + (a2 + a3);
+    acc += __shfl_xor(acc, 1, 64);
+    if ((tid & 1) == 0) sy[r] = acc;
+  }
+  if (owner) __syncthreads();
+  // V rows of this wave: acc[e] = V[vrow0 + 4 lq + e][16 ct + lr]
+  float part[4] = {0.f, 0.f, 0.f, 0.f};
+  if (v_active) {
+    float* sv = (second ? sVj : sVi) + ((wave & 3) * 16) * PITCH;
+    const bool to_global = nu_wg || (owner && !second);
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float* bl = sl + (16 * ct + lr) * PITCH + 4 * lq;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (u <= ct) {
+          const f4 fb = *reinterpret_cast<const f4*>(bl + 16 * u);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][e], fb[e], acc, 0, 0, 0);
+        }
+      }
+      const float yc = owner ? sy[16 * ct + lr] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sv[(4 * lq + e) * PITCH + 16 * ct + lr] = acc[e];
+        if (to_global) V[(size_t)(vrow0 + 4 * lq + e) * ldv + 16 * ct + lr] = acc[e];
+        part[e] = __builtin_fmaf(acc[e], yc, part[e]);
+      }
+    }
+  }
+  if (nu_wg) {                                     // the strip the panel launch would have left
+    for (int q = tid; q < NB * NB; q += 512) {
       const int k = q >> 7, c = q & 127;
       Zs[(size_t)k * ldz + c] = sl[c * PITCH + k];
     }
     return;
   }
-  int i = 0;
-  while ((i + 1) * (i + 2) / 2 <= (int)blockIdx.x) ++i;       // tile t -> (i, j), row-major over the lower triangle
-  const int j = blockIdx.x - i * (i + 1) / 2;
-  const bool owner = (j == 0);
-  {
-    const int row0 = 64 * i + wave * 16;
-    float part[4] = {0.f, 0.f, 0.f, 0.f};
-    v_rows(W, ldw, row0, sl, lane, [&](int ct, const f4& acc) {
-      const float yc = sy[16 * ct + lr];
+  if (owner && !second) {                          // mu += V_i y (the quaternion rows: below, from q')
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) part[e] += __shfl_xor(part[e], off, 64);
+    if (lr == 0) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        sVi[(wave * 16 + 4 * lq + e) * PITCH + 16 * ct + lr] = acc[e];
-        if (owner) {
-          V[(size_t)(row0 + 4 * lq + e) * ldv + 16 * ct + lr] = acc[e];
-          part[e] = __builtin_fmaf(acc[e], yc, part[e]);
-        }
-      }
-    });
-    if (owner) {
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) part[e] += __shfl_xor(part[e], off, 64);
-      if (lr == 0) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = row0 + 4 * lq + e;
-          if (r < n && !(r >= 3 && r < 7)) mu[r] += part[e];          // the quaternion rows: below, from q'
-        }
+        const int r = vrow0 + 4 * lq + e;
+        if (r < n && !(r >= 3 && r < 7)) mu[r] += part[e];
       }
     }
   }
-  const float* vj = sVi;
-  if (j != i) {
-    const int row0 = 64 * j + wave * 16;
-    v_rows(W, ldw, row0, sl, lane, [&](int ct, const f4& acc) {
+  // the Sigma values of this wave's two 16 x 16 blocks: requested now, used after the products
+  const int rb = wave >> 1, cb0 = 2 * (wave & 1);
+  float cin[2][4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) sVj[(wave * 16 + 4 * lq + e) * PITCH + 16 * ct + lr] = acc[e];
-    });
-    vj = sVj;
-  }
+  for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      cin[b2][e] = S[(size_t)(64 * i + 16 * rb + 4 * lq + e) * lds_ + 64 * j + 16 * (cb0 + b2) + lr];
   __syncthreads();                                 // V_i, V_j complete; nobody reads Linv any more
+  const float* vj = (j != i) ? sVj : sVi;
   if (owner && wave == 0) {
-    // q' = q_old + V[3:7] y (rows 3..6 of block j = 0), lane = column (two sweeps), butterfly sum
+    // q' = q_old + V[3:7] y (rows 3..6 of block 0), lane = column (two sweeps), butterfly sum
     for (int a = 0; a < 4; ++a) {
       float acc = vj[(3 + a) * PITCH + lane] * sy[lane];
       acc = __builtin_fmaf(vj[(3 + a) * PITCH + 64 + lane], sy[64 + lane], acc);
@@ -1533,48 +1580,49 @@ k_update_oneblock_small(const float* __restrict__ W, int ldw, const float* __res
       }
     }
   }
-  const int wr = wave >> 1, wc = wave & 1, h = lane >> 5, l31 = lane & 31;
-  f32x16 acc;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  f4 acc2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   {
-    const float* ap = sVi + (32 * wr + l31) * PITCH + 4 * h;
-    const float* bp = vj + (32 * wc + l31) * PITCH + 4 * h;
+    const float* ap = sVi + (16 * rb + lr) * PITCH + 4 * lq;
+    const float* bp0 = vj + (16 * cb0 + lr) * PITCH + 4 * lq;
+    const float* bp1 = bp0 + 16 * PITCH;
 #pragma unroll
-    for (int s8 = 0; s8 < 16; ++s8) {              // lane half h of MFMA e multiplies k = 8 s8 + 4 h + e on both operands
-      const f4 fa = *reinterpret_cast<const f4*>(ap + 8 * s8);
-      const f4 fb = *reinterpret_cast<const f4*>(bp + 8 * s8);
+    for (int u = 0; u < 8; ++u) {                  // lane (lr, lq) of MFMA (u, e) multiplies k = 16 u + 4 lq + e on both operands
+      const f4 fav = *reinterpret_cast<const f4*>(ap + 16 * u);
+      const f4 fb0 = *reinterpret_cast<const f4*>(bp0 + 16 * u);
+      const f4 fb1 = *reinterpret_cast<const f4*>(bp1 + 16 * u);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc, 0, 0, 0);
-    }
-  }
-  // acc reg e of lane -> row (e & 3) + 8 (e >> 2) + 4 h, column l31 of the wave's 32 x 32 block
-  const int tc = 32 * wc + l31;
-  if (!owner) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int tr = 32 * wr + (e & 3) + 8 * (e >> 2) + 4 * h;
-      const size_t gr = 64 * i + tr, gc = 64 * j + tc;
-      if (gr >= gc) {                              // a diagonal tile: its lower half, mirrored (the upper lanes must not touch it)
-        const float v = S[gr * lds_ + gc] - acc[e];
-        S[gr * lds_ + gc] = v;
-        S[gc * lds_ + gr] = v;
+      for (int e = 0; e < 4; ++e) {
+        acc2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fav[e], fb0[e], acc2[0], 0, 0, 0);
+        acc2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fav[e], fb1[e], acc2[1], 0, 0, 0);
       }
     }
+  }
+  // acc2[b][e] = (V_i V_j^T)[16 rb + 4 lq + e][16 (cb0 + b) + lr]
+  if (!owner) {
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const size_t gr = 64 * i + 16 * rb + 4 * lq + e, gc = 64 * j + 16 * (cb0 + b2) + lr;
+        if (gr >= gc) {                            // a diagonal tile: its lower half, mirrored (the upper lanes must not touch it)
+          const float v = cin[b2][e] - acc2[b2][e];
+          S[gr * lds_ + gc] = v;
+          S[gc * lds_ + gr] = v;
+        }
+      }
     return;
   }
   // tiles (i, 0): the downdated tile through LDS, the normalisation congruence on columns 3..6 (and, tile (0, 0),
   // rows 3..6 and the corner), then the tile and its mirror
   float* sT = sl;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int tr = 32 * wr + (e & 3) + 8 * (e >> 2) + 4 * h;
-    sT[tr * TP + tc] = S[(size_t)(64 * i + tr) * lds_ + tc] - acc[e];
-  }
+  for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sT[(16 * rb + 4 * lq + e) * TP + 16 * (cb0 + b2) + lr] = cin[b2][e] - acc2[b2][e];
   __syncthreads();                                 // (also: sJ is there)
   if (i == 0) {
     // the lower half is what counts: complete the image symmetrically first, so that rows and columns read the same values
-    for (int q = tid; q < 64 * 64; q += 256) {
+    for (int q = tid; q < 64 * 64; q += 512) {
       const int r = q >> 6, c = q & 63;
       if (c > r) sT[r * TP + c] = sT[c * TP + r];
     }
@@ -1622,7 +1670,7 @@ k_update_oneblock_small(const float* __restrict__ W, int ldw, const float* __res
       }
   }
   __syncthreads();
-  for (int q = tid; q < 64 * 64; q += 256) {
+  for (int q = tid; q < 64 * 64; q += 512) {
     const int r = q >> 6, c = q & 63;
     if (i == 0) {
       S[(size_t)r * lds_ + c] = (r >= c) ? sT[r * TP + c] : sT[c * TP + r];
