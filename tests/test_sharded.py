@@ -281,6 +281,8 @@ def test_hip_shard_world1_matches_plain_path_and_oracle(dtype):
         flt = _mk_hip(pkg, n_feat, capacity=2 * n_feat + 8, dtype=dtype)
         if shard:
             sharded.configure(flt, 0, 1)
+        else:
+            flt.set_option(6, 0)       # EKF_OPT_FUSED_LAUNCHES off: the launch-per-kernel sums the sharded path uses too
         ref = o.build_scenario(o.StructuredFilter, o.Config.kinect(), n_feat, dtype)
         hip_scenario(pkg, flt, ref, frames, dtype)
         flt.synchronize()

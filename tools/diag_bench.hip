@@ -1,6 +1,6 @@
-// Standalone timing + cross-check of the diagonal-block kernels (debug harness; not part of the library):
-// k_chol_diag_packed (inner blocking 16) against k_chol_diag32 (inner blocking 32), same input, L and L^-1 compared
-// with each other and with a host fp64 factorisation.
+// Standalone timing + cross-check of the diagonal-block kernel (debug harness; not part of the library):
+// k_chol_diag_packed against a host fp64 factorisation (L and L^-1), its time, its phases alone, and the s_memtime
+// stamps of wave 0 per 16-column block.   hipcc -O3 -std=c++17 --offload-arch=gfx950 -o diag_bench diag_bench.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
