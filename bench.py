@@ -498,33 +498,6 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
                                                 "algorithmic_bytes_per_step": b32}}
         flt3.close()
 
-        if n_feat >= 600:
-            # the reference's own operating point as a map (conf_sim.cfg:20-25: <= 35 features, all of them measured):
-            # N = 32, n = 205, 2 M + 3 <= 128 -- one diagonal block, so the update after the diagonal factor is ONE launch
-            # (k_update_oneblock_small) and the step is 5 launches: launch-latency-bound, reported as such
-            n32 = 32
-            fr32 = 400
-            px32, z32 = synthetic.measurement_stream(cfg, n32, fr32, sigma_px=SIGMA_Z_PX)
-            flt7 = FilterRing(pkg, cfg, n32, px32, z32, fr32)
-            d_z7 = torch.from_numpy(z32.reshape(fr32, -1)).to(dev).contiguous()
-            d_i7 = torch.arange(n32, dtype=torch.int32, device=dev)
-            bpf7 = 2 * n32 * 4
-            run_steps(flt7, d_z7, d_i7, n32, 0, 50, bpf7)
-            flt7.synchronize()
-            t0 = time.perf_counter()
-            run_steps(flt7, d_z7, d_i7, n32, 50, fr32 - 50, bpf7)
-            flt7.synchronize()
-            t1 = time.perf_counter()
-            t7 = (t1 - t0) / (fr32 - 50)
-            mu7 = flt7.at(fr32 - 1).getFullState()
-            result["secondary_N32_map"] = {
-                "what": "a 32-feature map (n = 205), every feature measured in every frame: the reference's operating point",
-                "value": round(1.0 / t7, 1), "unit": "updates/s", "ms_per_step": round(1e3 * t7, 4), "launches_per_step": 5,
-                "roofline": {"bound": "latency", "basis": "5 dependent launches of 5-10 us each (predict, W, S, diagonal factor, "
-                             "fused update); 3 n^2 s = 0.5 MB of traffic per step"},
-                "run_sane": bool(np.all(np.isfinite(mu7)) and abs(np.linalg.norm(mu7[3:7]) - 1) < 1e-4)}
-            flt7.close()
-
         if n_feat < 600:
             # small maps (configs[1], N = 200) are LATENCY-bound: one column chunk, a serial chain of a few block steps and
             # ~20 launches per step; say so with numbers next to the MFMA roofline of the (tiny) downdate
@@ -545,6 +518,10 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
                 "basis": "whole step: algorithmic bytes 3 n^2 s + 4 n m s + 2 m^2 s / ms_per_step -- far from either roofline: "
                          "the step is the sum of its launch latencies",
                 "launches_per_step": round(sum(c for _, c in per.values()), 1),
+                "launches_per_step_note": "counted under the per-kernel profile, which runs one launch per kernel; the timed run "
+                                          "(EKF_OPT_FUSED_LAUNCHES, default) needs " +
+                                          ("5: predict, W, S, diagonal factor, fused update (2M + 3 <= 128: one diagonal block)"
+                                           if 2 * n_feat + 3 <= 128 else "2 fewer (ekf_predict is one launch)"),
                 "chain_block_steps": int(round(per.get("chol_diag", (0.0, 0))[1])),
                 "chain_kernel_ms_per_step": round(chain, 4),
                 "chain_share_of_kernel_time": round(chain / max(sum(v for v, _ in per.values()), 1e-9), 3),
@@ -605,6 +582,35 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
             result["p_propagate_in_place"] = {"kernel": "k_strip_congruence<13>", "avg_launch_ms": round(ms / cnt, 4),
                                               "algorithmic_bytes_per_launch": 4.0 * 13 * n * 4}
         flt2.close()
+
+        if n_feat >= 600:
+            # (last of the GPU passes: its ~2000 tiny launches leave the clocks low for whatever follows)
+            # the reference's own operating point as a map (conf_sim.cfg:20-25: <= 35 features, all of them measured):
+            # N = 32, n = 205, 2 M + 3 <= 128 -- one diagonal block, so the update after the diagonal factor is ONE launch
+            # (k_update_oneblock_small) and the step is 5 launches: launch-latency-bound, reported as such
+            from ekf_monoslam_amd import synthetic
+            n32 = 32
+            fr32 = 400
+            px32, z32 = synthetic.measurement_stream(cfg, n32, fr32, sigma_px=SIGMA_Z_PX)
+            flt7 = FilterRing(pkg, cfg, n32, px32, z32, fr32)
+            d_z7 = torch.from_numpy(z32.reshape(fr32, -1)).to(dev).contiguous()
+            d_i7 = torch.arange(n32, dtype=torch.int32, device=dev)
+            bpf7 = 2 * n32 * 4
+            run_steps(flt7, d_z7, d_i7, n32, 0, 50, bpf7)
+            flt7.synchronize()
+            t0 = time.perf_counter()
+            run_steps(flt7, d_z7, d_i7, n32, 50, fr32 - 50, bpf7)
+            flt7.synchronize()
+            t1 = time.perf_counter()
+            t7 = (t1 - t0) / (fr32 - 50)
+            mu7 = flt7.at(fr32 - 1).getFullState()
+            result["secondary_N32_map"] = {
+                "what": "a 32-feature map (n = 205), every feature measured in every frame: the reference's operating point",
+                "value": round(1.0 / t7, 1), "unit": "updates/s", "ms_per_step": round(1e3 * t7, 4), "launches_per_step": 5,
+                "roofline": {"bound": "latency", "basis": "5 dependent launches of 5-10 us each (predict, W, S, diagonal factor, "
+                             "fused update); 3 n^2 s = 0.5 MB of traffic per step"},
+                "run_sane": bool(np.all(np.isfinite(mu7)) and abs(np.linalg.norm(mu7[3:7]) - 1) < 1e-4)}
+            flt7.close()
 
     if not args.no_cpu_baseline:
         threads = args.cpu_threads or len(os.sched_getaffinity(0))
