@@ -353,8 +353,8 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
     flt.synchronize()
     torch.cuda.synchronize()
     # EKF_OPT_PROFILE: HIP events around the dominant kernel only, and only in every 8th frame of the timed region
-    # (an event pair costs ~6 us of queue time; short runs time every frame)
-    sample = 8 if args.steps >= 64 else 1
+    # (an event pair costs ~6 us of queue time; runs of fewer than 16 steps time every frame)
+    sample = 8 if args.steps >= 16 else 1
     flt.set_option(2, 3 if sample == 8 else 1)
     flt.profile_reset()
     t0 = time.perf_counter()
