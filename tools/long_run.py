@@ -25,7 +25,8 @@ for k in range(steps):
     flt.predict()
     if k % 50 == 0 or k > steps - 3 or (WATCH and abs(k - WATCH) <= 3):
         h, vis, rem, S2 = flt.predictions()
-        d = np.diag(flt.getSigmaBlock(14, 14, 600, 600))
+        nb_ = min(600, flt.stateDim() - 14)
+        d = np.diag(flt.getSigmaBlock(14, 14, nb_, nb_))
         cam = np.diag(flt.getSigma())
         inn = np.sqrt(np.mean((h - z[k].reshape(-1, 2)) ** 2))
         zz = z[k].reshape(-1, 2)
