@@ -245,6 +245,8 @@ struct Filter : FilterBase {
                     d_frame, d_patch[0], d_patch[1], d_mpatch[0], d_mpatch[1], d_hb, d_zm, d_found, d_score, d_keep,
                     d_Vs[0], d_Vs[1], d_Vs[2], d_stage_send, d_stage_recv, d_archive, d_arch_idx, d_panel_tiles};
     for (void* p : ptrs) if (p) hipFree(p);
+    for (int s = 0; s < kInSlots; ++s) { if (h_in[s]) hipHostFree(h_in[s]); if (ev_in[s]) hipEventDestroy(ev_in[s]); }
+    if (h_pred) hipHostFree(h_pred);
     if (own_stream && stream) hipStreamDestroy(stream);
     if (stream_b) hipStreamDestroy(stream_b);
     if (stream_c) hipStreamDestroy(stream_c);
@@ -442,6 +444,32 @@ struct Filter : FilterBase {
       HIPCHK(hipStreamSynchronize(stream));   // host vectors may change right after
     }
     layout_dirty = false;
+    return EKF_OK;
+  }
+
+  // z (2 M scalars) and the index list (M ints) of a host caller -> d_z / d_midx through pinned slot `in_slot`
+  static constexpr int kInSlots = 4;
+  void* h_in[kInSlots] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_in[kInSlots] = {nullptr, nullptr, nullptr, nullptr};
+  bool in_used[kInSlots] = {false, false, false, false};
+  int in_slot = 0;
+  void* h_pred = nullptr;                               // host-mapped read-back buffer of ekf_get_predictions
+  int stage_inputs(const void* z, const int* idx, int M) {
+    const size_t zb = (size_t)2 * M * sizeof(T), ib = (size_t)M * sizeof(int);
+    const int s = in_slot;
+    in_slot = (in_slot + 1) % kInSlots;
+    if (!h_in[s]) {
+      HIPCHK(hipHostMalloc(&h_in[s], (size_t)capN * (2 * sizeof(T) + sizeof(int)) + 64, hipHostMallocDefault));
+      HIPCHK(hipEventCreateWithFlags(&ev_in[s], hipEventDisableTiming));
+    }
+    if (in_used[s]) HIPCHK(hipEventSynchronize(ev_in[s]));      // the copies that last used this slot are long done
+    char* base = static_cast<char*>(h_in[s]);
+    memcpy(base, z, zb);
+    memcpy(base + (size_t)2 * capN * sizeof(T), idx, ib);
+    HIPCHK(hipMemcpyAsync(d_z, base, zb, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(d_midx, base + (size_t)2 * capN * sizeof(T), ib, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipEventRecord(ev_in[s], stream));
+    in_used[s] = true;
     return EKF_OK;
   }
 
@@ -896,17 +924,27 @@ struct Filter : FilterBase {
     HIPCHK(hipSetDevice(device));
     if (!have_meas) FAIL(EKF_ERR_STATE, "no predictions: call ekf_predict / ekf_measure first");
     if (N == 0) return EKF_OK;
-    std::vector<unsigned char> fl(N);
-    std::vector<T> sd, vhc, vhf;
-    if (h) HIPCHK(hipMemcpyAsync(h, d_h, (size_t)N * 2 * sizeof(T), hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipMemcpyAsync(fl.data(), d_flags, N, hipMemcpyDeviceToHost, stream));
-    if (s2) { int rcs = ensure_sd(); if (rcs) return rcs; sd.resize((size_t)N * 4); HIPCHK(hipMemcpyAsync(sd.data(), d_Sd, sd.size() * sizeof(T), hipMemcpyDeviceToHost, stream)); }
+    // h, flags and the 2x2 blocks come back through ONE host-mapped pinned buffer the device writes (k_pack_predictions):
+    // one launch + one synchronisation per frame for the drop-in caller, instead of three staged copies
+    if (!h_pred) {
+      const size_t bytes = (size_t)capN * (6 * sizeof(T) + 1) + 64;
+      HIPCHK(hipHostMalloc(&h_pred, bytes, hipHostMallocDefault));
+    }
+    T* ph = reinterpret_cast<T*>(h_pred);
+    T* psd = ph + (size_t)2 * capN;
+    unsigned char* pfl = reinterpret_cast<unsigned char*>(psd + (size_t)4 * capN);
+    std::vector<T> vhc, vhf;
+    if (s2) { int rcs = ensure_sd(); if (rcs) return rcs; }
+    k_pack_predictions<T><<<(4 * N + 255) / 256, 256, 0, stream>>>(d_h, s2 ? d_Sd : static_cast<const T*>(nullptr), d_flags, N, ph,
+                                                                  psd, pfl);
     if (hc) { vhc.resize((size_t)N * 14); HIPCHK(hipMemcpyAsync(vhc.data(), d_Hc, vhc.size() * sizeof(T), hipMemcpyDeviceToHost, stream)); }
     if (hf) { vhf.resize((size_t)N * 12); HIPCHK(hipMemcpyAsync(vhf.data(), d_Hf, vhf.size() * sizeof(T), hipMemcpyDeviceToHost, stream)); }
     HIPCHK(hipStreamSynchronize(stream));
-    for (int i = 0; i < N; ++i) { if (vis) vis[i] = fl[i] & 1; if (rem) rem[i] = (fl[i] >> 1) & 1; }
+    if (h) memcpy(h, ph, (size_t)N * 2 * sizeof(T));
+    for (int i = 0; i < N; ++i) { if (vis) vis[i] = pfl[i] & 1; if (rem) rem[i] = (pfl[i] >> 1) & 1; }
     if (s2) {                                    // row-major 2x2 -> column-major
       T* o = static_cast<T*>(s2);
+      const T* sd = psd;
       for (int i = 0; i < N; ++i) { o[4 * i] = sd[4 * i]; o[4 * i + 1] = sd[4 * i + 2]; o[4 * i + 2] = sd[4 * i + 1]; o[4 * i + 3] = sd[4 * i + 3]; }
     }
     if (hc) { T* o = static_cast<T*>(hc); for (int i = 0; i < N; ++i) for (int a = 0; a < 2; ++a) for (int c = 0; c < 7; ++c) o[14 * i + c * 2 + a] = vhc[14 * i + a * 7 + c]; }
@@ -1190,8 +1228,10 @@ struct Filter : FilterBase {
         cur_z = static_cast<const T*>(z);
         cur_midx = idx;
       } else {
-        HIPCHK(hipMemcpyAsync(d_z, z, (size_t)2 * M * sizeof(T), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemcpyAsync(d_midx, idx, (size_t)M * sizeof(int), hipMemcpyHostToDevice, stream));
+        // host z / indices go through a small ring of pinned staging slots: the two copies are then truly asynchronous
+        // (a copy from pageable memory is staged by the runtime and costs the caller ~10 us each)
+        int rcs = stage_inputs(z, idx, M);
+        if (rcs) return rcs;
         sh_list.clear();
       }
     }

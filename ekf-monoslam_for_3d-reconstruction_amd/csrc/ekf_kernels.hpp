@@ -457,6 +457,18 @@ __global__ void __launch_bounds__(256) k_predict_fused(T* __restrict__ mu, T* __
   }
 }
 
+// What a drop-in caller reads back after every predict (ekf_get_predictions: h, flags, the 2x2 St blocks), packed into
+// ONE buffer -- host-mapped pinned memory, written straight from the device -- so that the read-back is one launch and
+// one synchronisation instead of three staged copies to pageable memory.  Layout: [N][2] h, [N][4] Sd (optional), N flag bytes.
+template <typename T>
+__global__ void k_pack_predictions(const T* __restrict__ h, const T* __restrict__ Sd, const unsigned char* __restrict__ flags,
+                                   int N, T* __restrict__ out_h, T* __restrict__ out_sd, unsigned char* __restrict__ out_fl) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < 2 * N) out_h[t] = h[t];
+  if (Sd && t < 4 * N) out_sd[t] = Sd[t];
+  if (t < N) out_fl[t] = flags[t];
+}
+
 // 2x2 diagonal block of St per feature: Hrow P Hrow^T + r_pix I with P = Sigma[idx, idx],
 // idx = [0..6, p..p+fs).  Only host-facing consumers need it (the gate of Patch::findMatch, the search
 // ellipses, the RANSAC hypotheses), so it is evaluated on demand, 16 lanes per feature: lane a owns row
