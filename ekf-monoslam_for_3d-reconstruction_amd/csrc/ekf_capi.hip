@@ -934,9 +934,16 @@ struct Filter : FilterBase {
     T* psd = ph + (size_t)2 * capN;
     unsigned char* pfl = reinterpret_cast<unsigned char*>(psd + (size_t)4 * capN);
     std::vector<T> vhc, vhf;
-    if (s2) { int rcs = ensure_sd(); if (rcs) return rcs; }
-    k_pack_predictions<T><<<(4 * N + 255) / 256, 256, 0, stream>>>(d_h, s2 ? d_Sd : static_cast<const T*>(nullptr), d_flags, N, ph,
-                                                                  psd, pfl);
+    if (s2 && !have_sd && !sh_on) {              // the 2x2 blocks and the packing in ONE launch
+      k_measure_sd<T><<<(16 * N + 255) / 256, 256, 0, stream>>>(S(), ld, d_pos, d_coding, 0, N, T(sigma_pixel_2), d_Hc, d_Hf,
+                                                               d_Sd, nullptr, 0, d_h, d_flags, ph, psd, pfl);
+      have_sd = true;
+    } else {
+      if (s2) { int rcs = ensure_sd(); if (rcs) return rcs; }
+      k_pack_predictions<T><<<(4 * N + 255) / 256, 256, 0, stream>>>(d_h, s2 ? d_Sd : static_cast<const T*>(nullptr), d_flags, N,
+                                                                    ph, psd, pfl);
+    }
+    HIPCHK(hipGetLastError());
     if (hc) { vhc.resize((size_t)N * 14); HIPCHK(hipMemcpyAsync(vhc.data(), d_Hc, vhc.size() * sizeof(T), hipMemcpyDeviceToHost, stream)); }
     if (hf) { vhf.resize((size_t)N * 12); HIPCHK(hipMemcpyAsync(vhf.data(), d_Hf, vhf.size() * sizeof(T), hipMemcpyDeviceToHost, stream)); }
     HIPCHK(hipStreamSynchronize(stream));

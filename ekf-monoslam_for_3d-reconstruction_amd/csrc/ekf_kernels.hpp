@@ -477,7 +477,11 @@ template <typename T>
 __global__ void k_measure_sd(const T* __restrict__ S, int ld, const int* __restrict__ pos,
                              const int* __restrict__ coding, int f_begin, int N, T r_pix,
                              const T* __restrict__ Hc, const T* __restrict__ Hf, T* __restrict__ Sd,
-                             const int* __restrict__ list = nullptr, int count = 0) {
+                             const int* __restrict__ list = nullptr, int count = 0,
+                             const T* __restrict__ h = nullptr, const unsigned char* __restrict__ flags = nullptr,
+                             T* __restrict__ out_h = nullptr, T* __restrict__ out_sd = nullptr,
+                             unsigned char* __restrict__ out_fl = nullptr) {
+  // out_h / out_sd / out_fl (ekf_get_predictions): the read-back buffer of k_pack_predictions filled in the same launch
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   int i = f_begin + (gid >> 4);
   const int a = gid & 15;
@@ -512,6 +516,15 @@ __global__ void k_measure_sd(const T* __restrict__ S, int ld, const int* __restr
     Sd[(size_t)i * 4 + 1] = s01;
     Sd[(size_t)i * 4 + 2] = s10;
     Sd[(size_t)i * 4 + 3] = s11 + r_pix;
+    if (out_sd) {
+      out_sd[(size_t)i * 4 + 0] = s00 + r_pix;
+      out_sd[(size_t)i * 4 + 1] = s01;
+      out_sd[(size_t)i * 4 + 2] = s10;
+      out_sd[(size_t)i * 4 + 3] = s11 + r_pix;
+      out_h[2 * i] = h[2 * i];
+      out_h[2 * i + 1] = h[2 * i + 1];
+      out_fl[i] = flags[i];
+    }
   }
 }
 
