@@ -209,6 +209,14 @@ struct Filter : FilterBase {
   float* d_score = nullptr;
   int* d_keep = nullptr;
   int opt_panel_direct = 1;                             // EKF_PANEL_DIRECT=0: panel through the general tile GEMM
+  int opt_solve_s2 = 1;                                 // EKF_SOLVE_S2: latency-bound solve launches on two wave groups (halves of K)
+  bool solve_s2_now = false;
+  // A solve launch of under ~one round of tiles is bounded by the K steps of its heaviest tile: two wave groups per
+  // workgroup then take half of K each (k_gemm_mfma<.., S2>).  The rule only looks at the chunk width and the size of the
+  // WHOLE state (never at the rows one rank holds), so the plain and the sharded path sum every element in the same order.
+  bool want_solve_s2(int width, int npad_live) const {
+    return kIsF32 && opt_mfma && opt_solve_s2 && (opt_solve_s2 > 1 || (width / 128) * (npad_live / 64) <= 2 * num_cus);   // (2: always, for A/B runs)
+  }
   int opt_fused = 1;                                    // EKF_OPT_FUSED_LAUNCHES: k_predict_fused, k_solve_state_oneblock, k_update_oneblock_small
   int opt_fuse_wu = 1;                                  // EKF_FUSE_WU: 0 never, 1 every overlapped chunk but the one before the last, 2 every overlapped chunk
   int env_chunks[8] = {}, env_nchunks = 0;               // EKF_CHUNKS="5,10,14,16": tuning knob (block steps)
@@ -398,6 +406,7 @@ struct Filter : FilterBase {
         HIPCHK(hipStreamCreateWithFlags(&stream_c, hipStreamNonBlocking));
       }
       if (const char* e = getenv("EKF_FUSE_WU")) opt_fuse_wu = atoi(e);
+      if (const char* e = getenv("EKF_SOLVE_S2")) opt_solve_s2 = atoi(e);
       if (const char* e = getenv("EKF_FUSED_LAUNCHES")) opt_fused = atoi(e) ? 1 : 0;   // = EKF_OPT_FUSED_LAUNCHES, for A/B runs
       if (const char* e = getenv("EKF_PANEL_DIRECT")) opt_panel_direct = atoi(e);
       if (const char* e = getenv("EKF_SPLIT_TAIL")) opt_split_tail = atoi(e);
@@ -983,6 +992,12 @@ struct Filter : FilterBase {
     }
     if constexpr (kIsF32) {
       if (opt_mfma) {
+        if constexpr (ROLE == ROLE_SOLVE) {
+          if (solve_s2_now) {
+            k_gemm_mfma<ROLE, BT, TM, TN, true><<<grid, 512, 0, st>>>(g);
+            return;
+          }
+        }
         k_gemm_mfma<ROLE, BT, TM, TN><<<grid, 256, 0, st>>>(g);
         return;
       }
@@ -1314,6 +1329,7 @@ struct Filter : FilterBase {
         }
       } else {
         Scope sc(this, KID_SOLVE, ss);                    // column tiles of the chunk, heaviest first
+        solve_s2_now = want_solve_s2(width, npad_live);
         const int wt = width / tile;
         const int slots = 2 * (overlap ? num_cus - reserved_cus : num_cus);
         if (kIsF32 && opt_mfma && 4 * wt * ntr < slots) { // small map: 64 x 64 tiles
@@ -2453,6 +2469,7 @@ struct Filter : FilterBase {
         if (rr.count == 0) continue;
         const size_t off = (size_t)rr.r0 * ldy;
         { Scope sc(this, KID_SOLVE, ss);
+          solve_s2_now = want_solve_s2(width, npad_live);
           gemm<ROLE_SOLVE, true>(d_W + off + c0, ldy, Zs + c0, ldy, d_V + off + c0, ldy, rr.count, width, width, T(1), T(0),
                                  0, 0, 0, 1, 0, ss); }
       }

@@ -363,11 +363,11 @@ __global__ void __launch_bounds__(256) k_gemm_valu(GemmArgs g) {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int ROLE, bool BT, int TM = 128, int TN = 128>
+template <int ROLE, bool BT, int TM = 128, int TN = 128, bool S2 = false>
 // Register budget: two 128 x 128 workgroups per CU (two waves per SIMD each); the 64 x 64 chain tiles (ROLE_TRAILING)
 // are held to 80 registers so that one of them fits on a CU BESIDE two downdate workgroups (2 x 216 + 80 <= 512, LDS
 // 2 x 64 + 32 KiB): the trailing update of the chain then runs on every CU, not only on the ones the second stream leaves.
-__global__ void __launch_bounds__(256, (ROLE == ROLE_TRAILING && TM == 64 && TN == 64) ? 6 : 2) k_gemm_mfma(GemmArgs g) {
+__global__ void __launch_bounds__(S2 ? 512 : 256, S2 ? 1 : ((ROLE == ROLE_TRAILING && TM == 64 && TN == 64) ? 6 : 2)) k_gemm_mfma(GemmArgs g) {
   // TM x TN output tile (64 or 128 each), 4 waves as 2 x 2, each wave (TM/2) x (TN/2) = MI x NJ
   // accumulators of 32x32.  The small shapes exist for the latency-bound launches (chain tiles, tail of
   // the triangular solve): same flop, 2-4x the workgroups.
@@ -384,13 +384,19 @@ __global__ void __launch_bounds__(256, (ROLE == ROLE_TRAILING && TM == 64 && TN 
   const int lda = g.lda;
   constexpr bool DUAL = (ROLE == ROLE_DOWNDATE) && !BT && TM == 128 && TN == 128;   // GemmArgs::B2 / C2
   const float alpha = float(g.alpha), beta = float(g.beta);
-  __shared__ f32x4 lds[2 * NQ * (TM + TN)];   // two stages of {A image, B image}: one barrier per K step
+  // S2 (the latency-bound launches of the triangular solve: under one round of tiles, each bounded by the K steps of its
+  // own loop): TWO groups of four waves per workgroup, group g takes every second K step (parity g) of the tile's K range
+  // with its own LDS stages; both run the same number of steps (K is a multiple of 64), so the workgroup barriers of the
+  // loop stay in step; group 1 then hands its accumulators over through LDS and group 0 stores the sum.
+  __shared__ f32x4 lds[(S2 ? 2 : 1) * 2 * NQ * (TM + TN)];   // per group: two stages of {A image, B image}: one barrier per K step
   // the queue's hand-over word lives in the first LDS slot (free between tiles: the body's first barrier separates its
   // last reader from the first stage store): the workgroup then takes exactly 64 KiB (32 KiB for 64 x 64), and a
   // 64 x 64 chain tile fits beside two 128 x 128 workgroups on a CU
   int* const s_tile_p = reinterpret_cast<int*>(lds);
   constexpr int STAGE = NQ * (TM + TN);
-  const int tid = threadIdx.x;
+  const int tid = S2 ? (threadIdx.x & 255) : threadIdx.x;
+  const int grp = S2 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;
+  const int lbase = S2 ? grp * 2 * STAGE : 0;     // this group's stages
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WC, wc = wave % WC;
   if (ROLE == ROLE_PANEL || ROLE == ROLE_TRAILING) __builtin_amdgcn_s_setprio(2);   // part of the serial chain
@@ -410,7 +416,11 @@ __global__ void __launch_bounds__(256, (ROLE == ROLE_TRAILING && TM == 64 && TN 
   const int grow0 = g.row_off + bi * TMb, gcol0 = g.col_off + bj * TN;
   if (tri && tri != 3 && grow0 + TMb <= gcol0) return;
   if (g.zrow && grow0 >= g.zrow && gcol0 >= g.zcol_end) return;
-  const int K = g.ktri ? min(g.K, (bj + g.ktile_off + 1) * TN) : g.K;
+  const int Kall = g.ktri ? min(g.K, (bj + g.ktile_off + 1) * TN) : g.K;
+  // S2: group g takes the K steps of parity g (k in [32 (2 s + g), 32 (2 s + g + 1))): both groups run Kall / 64 steps, and
+  // which group adds a given k does not depend on the tile shape (the K range of a triangular tile does)
+  const int K = S2 ? Kall / 2 : Kall;
+  const int koff = S2 ? grp * BK : 0;
   // A staging: TMb*8 float4 per tile, PA per lane; 8 consecutive lanes cover 128 B of a row
   const float* Ag[PA];
   const float* Bg[4];
@@ -419,7 +429,7 @@ __global__ void __launch_bounds__(256, (ROLE == ROLE_TRAILING && TM == 64 && TN 
   for (int p = 0; p < PA; ++p) {
     const int idx = tid + NT * p;
     const int row = idx >> 3, q = idx & 7;
-    Ag[p] = A + (size_t)(bi * TMb + row) * lda + q * 4;
+    Ag[p] = A + (size_t)(bi * TMb + row) * lda + q * 4 + koff;
     aslot[p] = q * TMb + (row ^ q);
   }
   // NN mode: lane owns k-quad qk and column quad cq: rows 4qk+p (p < 4), 4 columns; TN = 64 uses lanes < 128
@@ -430,10 +440,10 @@ __global__ void __launch_bounds__(256, (ROLE == ROLE_TRAILING && TM == 64 && TN 
     if (!BT) {
       const int idx = tid + NT * p;
       const int row = idx >> 3, q = idx & 7;
-      Bg[p] = (p < PB) ? B + (size_t)(bj * TN + row) * ldb + q * 4 : B;
+      Bg[p] = (p < PB) ? B + (size_t)(bj * TN + row) * ldb + q * 4 + koff : B;
       bslot[p] = q * TN + (row ^ q);
     } else {
-      Bg[p] = B + (size_t)(4 * (bt_active ? qk : 0) + p) * ldb + bj * TN + 4 * cq;
+      Bg[p] = B + (size_t)(koff + 4 * (bt_active ? qk : 0) + p) * ldb + bj * TN + 4 * cq;
       bslot[p] = qk * TN + ((4 * cq + p) ^ qk);
     }
   }
@@ -452,7 +462,8 @@ __global__ void __launch_bounds__(256, (ROLE == ROLE_TRAILING && TM == 64 && TN 
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   constexpr int PBL = BT ? 4 : PB;             // B float4 loads per lane
   f32x4 ra[PA], rb[4];
-  auto load_tile = [&](int k0) {
+  auto load_tile = [&](int k0_) {
+    const int k0 = S2 ? 2 * k0_ : k0_;
 #pragma unroll
     for (int p = 0; p < PA; ++p) ra[p] = *reinterpret_cast<const f32x4*>(Ag[p] + k0);
 #pragma unroll
@@ -460,7 +471,7 @@ __global__ void __launch_bounds__(256, (ROLE == ROLE_TRAILING && TM == 64 && TN 
       rb[p] = BT ? *reinterpret_cast<const f32x4*>(Bg[p] + (size_t)k0 * ldb) : *reinterpret_cast<const f32x4*>(Bg[p] + k0);
   };
   auto store_tile = [&](int stage) {
-    f32x4* As = lds + stage * STAGE;
+    f32x4* As = S2 ? lds + lbase + stage * STAGE : lds + stage * STAGE;
     f32x4* Bs = As + NQ * TMb;
 #pragma unroll
     for (int p = 0; p < PA; ++p) As[aslot[p]] = ra[p];
@@ -484,7 +495,7 @@ __global__ void __launch_bounds__(256, (ROLE == ROLE_TRAILING && TM == 64 && TN 
   static_assert(NG % 2 == 0, "fragment ping-pong assumes an even number of groups");
   f32x4 fa[2][MI], fb[2][NJ];
   auto read_frag = [&](int stage_, int s, int buf) {
-    const f32x4* As = lds + stage_ * STAGE;
+    const f32x4* As = S2 ? lds + lbase + stage_ * STAGE : lds + stage_ * STAGE;
     const f32x4* Bs = As + NQ * TMb;
     const int q = 2 * s + h;
 #pragma unroll
@@ -560,6 +571,34 @@ __global__ void __launch_bounds__(256, (ROLE == ROLE_TRAILING && TM == 64 && TN 
     for (; k0 + 2 * BK < K; k0 += BK) kstep(yes{}, yes{}, k0);
     if (k0 + BK < K) { kstep(yes{}, no{}, k0); k0 += BK; }
     kstep(no{}, no{}, k0);
+  }
+  if constexpr (S2) {
+    // group 1's accumulators -> its own (now idle) LDS stages -> added into group 0's, which stores the tile
+    __syncthreads();                               // both groups are out of their loops
+    f32x4* xch = lds + 2 * STAGE;
+    if (grp == 1) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            f32x4 o = {acc[i][j][4 * qd], acc[i][j][4 * qd + 1], acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3]};
+            xch[((i * NJ + j) * 4 + qd) * NT + tid] = o;
+          }
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const f32x4 o = xch[((i * NJ + j) * 4 + qd) * NT + tid];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][4 * qd + e] += o[e];
+        }
   }
   // epilogue: acc reg e of lane -> row (e&3) + 8*(e>>2) + 4*h, col l31 of the 32x32 tile
   const bool mirror = (TMb == TN || SPLIT) && ((tri == 2 && grow0 >= gcol0 + TN) || (tri == 3 && listed_mirror));

@@ -1009,3 +1009,35 @@ def test_fused_launches_match_launch_per_kernel(n_feat):
         assert np.array_equal(S1, S1.T)
     g1.synchronize()
     g0.synchronize()
+
+
+def test_two_group_solve_agrees_with_the_single_group_solve(monkeypatch):
+    """Latency-bound solve launches run every tile on two groups of four waves, each taking every second K step
+    (k_gemm_mfma<.., S2>): the same products summed in two partial sums, i.e. fp32 rounding against the one-group kernel
+    (EKF_SOLVE_S2=0), and the selection rule looks only at the chunk width and the size of the whole state, so it cannot
+    differ between the plain and the sharded path (their bit-identity is asserted in tests/test_sharded.py)."""
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from ekf_monoslam_amd import synthetic
+    cfg = pkg.kinect_config()
+    n_feat = 640
+    px0, z = synthetic.measurement_stream(cfg, n_feat, 3, sigma_px=0.5)
+    idx = np.arange(n_feat, dtype=np.int32)
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("EKF_SOLVE_S2", mode)             # read when the filter is created
+        f = pkg.VSlamFilter(cfg, capacity_features=n_feat)
+        f.setDt(1.0 / 30.0)
+        for (u, v) in px0:
+            assert f.addFeature((u, v)) == 1
+        for k in range(2):
+            f.predict()
+            f.update(z[k].reshape(-1), idx)
+        f.synchronize()
+        outs.append((f.getFullState(), f.getFullSigma()))
+        f.close()
+    monkeypatch.delenv("EKF_SOLVE_S2", raising=False)
+    assert not np.array_equal(outs[0][1], outs[1][1])        # the two-group path did run
+    assert bound("mu two-group vs one-group solve", relf(outs[0][0], outs[1][0]), 5e-6)
+    assert bound("Sigma two-group vs one-group solve", relf(outs[0][1], outs[1][1]), 2e-5)
+    assert np.array_equal(outs[0][1], outs[0][1].T)
