@@ -1466,10 +1466,6 @@ k_solve_state_oneblock(const float* __restrict__ W, int ldw, const float* __rest
   }
 }
 
-template <typename T, int K>
-__device__ __forceinline__ void strip_congruence_body(T* __restrict__ S, int ld, int n, int o, const T* sJ, const T* Qs,
-                                                      T* sC, T* sA, int bid, int tid, int nthreads);
-
 // Small maps (every 64 x 64 lower tile of Sigma gets its own workgroup, all of them side by side): the WHOLE rest of the
 // update after the diagonal factor as one launch, with no hand-over between workgroups.  Workgroup t = tile (i, j),
 // j <= i, 8 waves: waves 0..3 form the row block V_i, waves 4..7 V_j (2 x 2 MFLOP per workgroup, all tiles in
