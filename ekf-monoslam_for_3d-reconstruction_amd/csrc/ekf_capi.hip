@@ -1094,10 +1094,15 @@ struct Filter : FilterBase {
       // default: three chunks ending at 3/16, 8/16 and 1 of the chain (tools/sweep_chunks.sh: the first chunk is
       // exposed, so it is short; every further chunk re-reads Sigma once in its downdate, so there are few; with the
       // chain at ~47 us per step the second stream, not the chain, decides where the last chunk may start)
+      // Long chains (>= 32 steps; round 3, tools/knob_ab.py: 32 steps 6/16 -> 4/14: -1 %, 63 steps 12/32 -> 5/25: -2.6 %): the chain
+      // is hidden there whatever the plan, so the first two chunks shrink in proportion -- less exposed start-up, and a
+      // wider last chunk, whose downdate has every CU
       static const int kEnd16[3] = {3, 8, 16};
       int k = 0, prev = 0;
       for (int g = 0; g < 3; ++g) {
         int e = (g == 2) ? nsteps : (nsteps * kEnd16[g] + 8) / 16;
+        if (nsteps >= 32 && g == 0) e = 3 + (nsteps - 16) / 16;
+        if (nsteps >= 32 && g == 1) e = (int)(2.0 + 0.36 * nsteps + 0.5);
         if (e > prev) { cend[k++] = e; prev = e; }
       }
       return k;
