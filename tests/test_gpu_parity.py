@@ -1044,3 +1044,27 @@ def test_two_group_solve_agrees_with_the_single_group_solve(monkeypatch):
     assert bound("mu two-group vs one-group solve", relf(outs[0][0], outs[1][0]), 5e-6)
     assert bound("Sigma two-group vs one-group solve", relf(outs[0][1], outs[1][1]), 2e-5)
     assert np.array_equal(outs[0][1], outs[0][1].T)
+
+
+def test_host_inputs_through_the_pinned_ring_without_synchronisation():
+    """ekf_update stages host z / indices through a ring of four pinned slots and returns at once; ten frames are queued
+    without any read-back or synchronisation in between (the ring wraps twice, the caller's buffer is overwritten right
+    after every call), then the state is compared with the oracle's."""
+    ref, g = make_pair(24, np.float32)
+    zbuf = np.zeros(2 * 24, np.float32)
+    for k in range(10):
+        ref.predict()
+        g.predict()
+        vis = ref.visible_indices()
+        z = o.synthetic_measurements(ref, vis, seed=900 + k)
+        ref.update(z, vis)
+        zbuf[:z.size] = np.asarray(z, np.float32).reshape(-1)
+        g.update(zbuf[:z.size], vis)
+        zbuf[:] = np.nan                                         # the call has copied its inputs: this must not matter
+    g.synchronize()
+    mu, S = gpu_state(g)
+    assert bound("mu after 10 queued frames", relf(mu, ref.mu), TOL[np.float32]["mu"] * 20)
+    assert bound("Sigma after 10 queued frames", relf(S, ref.Sigma), TOL[np.float32]["S"] * 10)
+    g.predict()
+    h, vis_g, rem, S2 = g.predictions()                           # the read-back buffer after the queue has drained
+    assert np.all(np.isfinite(h)) and np.all(np.isfinite(S2))
