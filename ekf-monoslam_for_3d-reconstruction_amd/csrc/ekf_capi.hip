@@ -255,6 +255,8 @@ struct Filter : FilterBase {
     for (void* p : ptrs) if (p) hipFree(p);
     for (int s = 0; s < kInSlots; ++s) { if (h_in[s]) hipHostFree(h_in[s]); if (ev_in[s]) hipEventDestroy(ev_in[s]); }
     if (h_pred) hipHostFree(h_pred);
+    if (h_ransac) hipHostFree(h_ransac);
+    if (h_gate) hipHostFree(h_gate);
     if (own_stream && stream) hipStreamDestroy(stream);
     if (stream_b) hipStreamDestroy(stream_b);
     if (stream_c) hipStreamDestroy(stream_c);
@@ -463,12 +465,19 @@ struct Filter : FilterBase {
   bool in_used[kInSlots] = {false, false, false, false};
   int in_slot = 0;
   void* h_pred = nullptr;                               // host-mapped read-back buffer of ekf_get_predictions
-  int stage_inputs(const void* z, const int* idx, int M) {
+  void* h_ransac = nullptr;                             // ... of ekf_ransac_1point: counts, camera pose, small inlier masks
+  static constexpr size_t kRansacMaskBytes = 65536;
+  const unsigned char* ransac_mask_host = nullptr;      // the mask of the last ransac() call, if it came back with the counts
+  int ransac_mask_M = 0;
+  double ransac_cam[7] = {0, 0, 0, 0, 0, 0, 0};
+  bool ransac_cam_valid = false;
+  void* h_gate = nullptr;                               // host-mapped gate flags of ekf_rescue_high_innovation
+  int stage_inputs(const void* z, const int* idx, int M, const void* cam7 = nullptr) {
     const size_t zb = (size_t)2 * M * sizeof(T), ib = (size_t)M * sizeof(int);
     const int s = in_slot;
     in_slot = (in_slot + 1) % kInSlots;
     if (!h_in[s]) {
-      HIPCHK(hipHostMalloc(&h_in[s], (size_t)capN * (2 * sizeof(T) + sizeof(int)) + 64, hipHostMallocDefault));
+      HIPCHK(hipHostMalloc(&h_in[s], (size_t)capN * (2 * sizeof(T) + sizeof(int)) + 8 * sizeof(T) + 64, hipHostMallocDefault));
       HIPCHK(hipEventCreateWithFlags(&ev_in[s], hipEventDisableTiming));
     }
     if (in_used[s]) HIPCHK(hipEventSynchronize(ev_in[s]));      // the copies that last used this slot are long done
@@ -477,6 +486,11 @@ struct Filter : FilterBase {
     memcpy(base + (size_t)2 * capN * sizeof(T), idx, ib);
     HIPCHK(hipMemcpyAsync(d_z, base, zb, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(d_midx, base + (size_t)2 * capN * sizeof(T), ib, hipMemcpyHostToDevice, stream));
+    if (cam7) {                                         // (the rescue's camera pose of the state before the first update)
+      char* pc7 = base + (size_t)capN * (2 * sizeof(T) + sizeof(int));
+      memcpy(pc7, cam7, 7 * sizeof(T));
+      HIPCHK(hipMemcpyAsync(d_tmp, pc7, 7 * sizeof(T), hipMemcpyHostToDevice, stream));
+    }
     HIPCHK(hipEventRecord(ev_in[s], stream));
     in_used[s] = true;
     return EKF_OK;
@@ -1119,7 +1133,7 @@ struct Filter : FilterBase {
 
   // W, S (and nu) for a measured set already resident in d_midx / d_z.
   int build_innovation(int M, int plane, bool with_nu, int* m_out, int* m_pad_out, const ChunkTab* tab = nullptr,
-                       int strip_rows = 0) {
+                       int strip_rows = 0, bool w_only = false) {
     const int nb = NB();
     const int m = 2 * M + (plane ? 3 : 0);
     const int m_pad = round_up(m, nb);
@@ -1155,7 +1169,7 @@ struct Filter : FilterBase {
                                                   m_pad, 0, n, N, zq, d_h, mu(), nuq, d_counters, d_status, d_scr + SCR_QOLD);
       }
     }
-    {
+    if (!w_only) {                      // (the 1-point RANSAC reads W only)
       Scope sc(this, KID_INNOVATION_COV);
       T* zid = tab ? d_Y + (size_t)m_pad * ldy : nullptr;
       const ChunkTab ct = tab ? *tab : ChunkTab{0, {}};
@@ -1632,12 +1646,13 @@ struct Filter : FilterBase {
     int rc = sync_layout();
     if (rc) return rc;
     if (sh_on) { rc = check_ascending(idx, M); if (rc) return rc; }
-    HIPCHK(hipMemcpyAsync(d_z, z, (size_t)2 * M * sizeof(T), hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemcpyAsync(d_midx, idx, (size_t)M * sizeof(int), hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemcpyAsync(d_tmp, cam_before, 7 * sizeof(T), hipMemcpyHostToDevice, stream));
+    rc = stage_inputs(z, idx, M, cam_before);          // pinned staging ring -> d_z / d_midx / d_tmp
+    if (rc) return rc;
     sh_list.clear();
     if (!d_ibuf) HIPCHK(hipMalloc(&d_ibuf, (size_t)std::max(capN, 1) * 3 * sizeof(int)));
-    unsigned char* d_out = reinterpret_cast<unsigned char*>(d_ibuf);
+    // the gate flags go straight into host-mapped pinned memory (one synchronisation, no staged copy)
+    if (!h_gate) HIPCHK(hipHostMalloc(&h_gate, (size_t)std::max(capN, 1) + 64, hipHostMallocDefault));
+    unsigned char* d_out = static_cast<unsigned char*>(h_gate);
     {
       Scope sc(this, KID_MEASURE);
       k_measure<T><<<(M + 63) / 64, 64, 0, stream>>>(mu(), d_pos, d_coding, 0, N, cam, d_h, d_Hc, d_Hf, d_flags, d_midx, M,
@@ -1658,8 +1673,9 @@ struct Filter : FilterBase {
       }
       k_chi2_gate<T><<<(M + 127) / 128, 128, 0, stream>>>(d_h, d_Sd, d_z, d_midx, M, T(thr), d_out);
     }
-    HIPCHK(hipMemcpyAsync(out, d_out, M, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(stream));
+    memcpy(out, d_out, (size_t)M);
     have_meas = true;          // the listed features carry fresh h / H (the others keep older ones)
     have_sd = false;           // the 2x2 blocks just written have no measurement noise: not the St blocks
     return EKF_OK;
@@ -1744,13 +1760,13 @@ struct Filter : FilterBase {
     if (!have_meas) FAIL(EKF_ERR_STATE, "ekf_ransac_1point needs ekf_predict / ekf_measure first");
     for (int k = 0; k < M; ++k)
       if (idx[k] < 0 || idx[k] >= N) FAIL(EKF_ERR_ARG, "feature index out of range");
-    HIPCHK(hipMemcpyAsync(d_z, z, (size_t)2 * M * sizeof(T), hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemcpyAsync(d_midx, idx, (size_t)M * sizeof(int), hipMemcpyHostToDevice, stream));
+    { int rcs = stage_inputs(z, idx, M); if (rcs) return rcs; }   // pinned staging ring -> d_z / d_midx
     sh_list.clear();
     int m = 0, m_pad = 0;
+    ransac_mask_host = nullptr;
     { int rcs = ensure_sd(); if (rcs) return rcs; }
     if (sh_on) return shard_ransac(idx, M, thr, counts, inl, best);
-    int rc = build_innovation(M, 0, false, &m, &m_pad);       // W = Sigma H^T for the listed features
+    int rc = build_innovation(M, 0, false, &m, &m_pad, nullptr, 0, true);       // W = Sigma H^T for the listed features
     if (rc) return rc;
     have_update = false;
     if (!d_ibuf) HIPCHK(hipMalloc(&d_ibuf, (size_t)std::max(capN, 1) * 3 * sizeof(int)));
@@ -1767,16 +1783,32 @@ struct Filter : FilterBase {
                                                 T(thr), d_rmask);
       k_ransac_count<<<(M + 127) / 128, 128, 0, stream>>>(d_rmask, M, d_ibuf);
     }
-    std::vector<int> cnt(M);
-    HIPCHK(hipMemcpyAsync(cnt.data(), d_ibuf, (size_t)M * sizeof(int), hipMemcpyDeviceToHost, stream));
+    // ONE read-back: counts, the camera pose and -- up to 64 KiB -- the whole inlier mask through a host-mapped pinned
+    // buffer the device writes (k_pack_ransac), one synchronisation
+    if (!h_ransac) HIPCHK(hipHostMalloc(&h_ransac, (size_t)capN * sizeof(int) + 8 * sizeof(T) + kRansacMaskBytes + 64,
+                                        hipHostMallocDefault));
+    int* pc = reinterpret_cast<int*>(h_ransac);
+    T* pcam = reinterpret_cast<T*>(pc + capN);
+    unsigned char* pmask = reinterpret_cast<unsigned char*>(pcam + 8);
+    const int with_mask = ((size_t)M * M <= kRansacMaskBytes) ? 1 : 0;
+    k_pack_ransac<T><<<with_mask ? std::max(1, std::min(64, (M * M + 255) / 256)) : (M + 255) / 256, 256, 0, stream>>>(
+        d_ibuf, M, mu(), d_rmask, with_mask, pc, pcam, pmask);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(stream));
+    for (int k = 0; k < 7; ++k) ransac_cam[k] = double(pcam[k]);
+    ransac_cam_valid = true;
+    if (with_mask) { ransac_mask_host = pmask; ransac_mask_M = M; }
     int b = 0;
-    for (int k = 1; k < M; ++k) if (cnt[k] > cnt[b]) b = k;
-    if (counts) for (int k = 0; k < M; ++k) counts[k] = cnt[k];
+    for (int k = 1; k < M; ++k) if (pc[k] > pc[b]) b = k;
+    if (counts) for (int k = 0; k < M; ++k) counts[k] = pc[k];
     if (best) *best = b;
     if (inl) {
-      HIPCHK(hipMemcpy2DAsync(inl, 1, d_rmask + b, (size_t)M, 1, M, hipMemcpyDeviceToHost, stream));
-      HIPCHK(hipStreamSynchronize(stream));
+      if (with_mask) {
+        for (int k = 0; k < M; ++k) inl[k] = pmask[(size_t)k * M + b];
+      } else {
+        HIPCHK(hipMemcpy2DAsync(inl, 1, d_rmask + b, (size_t)M, 1, M, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+      }
     }
     return EKF_OK;
   }
@@ -1846,8 +1878,13 @@ struct Filter : FilterBase {
       if (rc) return rc;
     }
     T cam_before[7];
-    HIPCHK(hipMemcpyAsync(cam_before, mu(), sizeof(cam_before), hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
+    if (M > 0 && !sh_on && ransac_cam_valid) {                   // came back with the counts (no update since)
+      for (int k = 0; k < 7; ++k) cam_before[k] = T(ransac_cam[k]);
+    } else {
+      HIPCHK(hipMemcpyAsync(cam_before, mu(), sizeof(cam_before), hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+    }
+    ransac_cam_valid = false;
     std::vector<T> zl, zr;
     std::vector<int> il, ir, kr;
     for (int k = 0; k < M; ++k) {
@@ -2203,6 +2240,10 @@ struct Filter : FilterBase {
   // column `sel` of the inlier mask of the last ekf_ransac_1point (rows = list positions); under sharding every rank
   // contributes the rows of its own listed features
   int fetch_mask_column(int sel, const int* idx, int M, unsigned char* out) {
+    if (!sh_on && ransac_mask_host && ransac_mask_M == M) {       // it came back with the counts
+      for (int k = 0; k < M; ++k) out[k] = ransac_mask_host[(size_t)k * M + sel];
+      return EKF_OK;
+    }
     if (!sh_on) {
       HIPCHK(hipMemcpy2DAsync(out, 1, d_rmask + sel, (size_t)M, 1, M, hipMemcpyDeviceToHost, stream));
       HIPCHK(hipStreamSynchronize(stream));

@@ -847,6 +847,21 @@ __global__ void k_ransac_count(const unsigned char* __restrict__ mask, int M, in
   counts[k] = c;
 }
 
+// What the host needs back after the hypotheses are evaluated (ekf_ransac_1point / ekf_update_two_stage), in ONE
+// host-mapped pinned buffer: the counts, the camera pose (r, q: the "state before the first update" the rescue
+// linearises around) and -- while it is small -- the whole inlier mask, so that picking a hypothesis' column needs no
+// second round trip.  Layout: [M] int counts, [8] T (7 used), then M x M bytes (with_mask).
+template <typename T>
+__global__ void k_pack_ransac(const int* __restrict__ counts, int M, const T* __restrict__ mu,
+                              const unsigned char* __restrict__ mask, int with_mask, int* __restrict__ out_counts,
+                              T* __restrict__ out_cam, unsigned char* __restrict__ out_mask) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < M) out_counts[t] = counts[t];
+  if (t < 7) out_cam[t] = mu[t];
+  if (with_mask)
+    for (size_t q = t; q < (size_t)M * M; q += (size_t)gridDim.x * blockDim.x) out_mask[q] = mask[q];
+}
+
 // f3: map export, one lane per feature: the N x 12 table of RosVSLAM::getPointsFeatures
 // (RosVSLAMRansac.cpp:340-418): [X Y Z] * map_scale, then the 3x3 covariance block row by row.
 // The reference fills rows of XYZ features only (inverse-depth rows stay zero, :360-375); with
