@@ -257,6 +257,7 @@ struct Filter : FilterBase {
     if (h_pred) hipHostFree(h_pred);
     if (h_ransac) hipHostFree(h_ransac);
     if (h_gate) hipHostFree(h_gate);
+    if (h_rb) hipHostFree(h_rb);
     if (own_stream && stream) hipStreamDestroy(stream);
     if (stream_b) hipStreamDestroy(stream_b);
     if (stream_c) hipStreamDestroy(stream_c);
@@ -496,10 +497,56 @@ struct Filter : FilterBase {
     return EKF_OK;
   }
 
-  int check_status() {
+  // Small device -> host reads of the getters: through ONE pinned bounce buffer, several pieces and the status words per
+  // synchronisation (a copy into pageable memory is staged by the runtime and costs ~25 us; every getter used to pay that
+  // twice, once for its data and once for the status words).
+  void* h_rb = nullptr;
+  size_t rb_cap = 0, rb_off = 0;
+  struct RbPiece { void* dst; size_t off, bytes; };
+  std::vector<RbPiece> rb_pend;
+  int rb_reserve(size_t bytes) {
+    if (rb_off + bytes + 64 <= rb_cap) return EKF_OK;
+    if (!rb_pend.empty()) FAIL(EKF_ERR_STATE, "read-back buffer grown with pieces pending");
+    const size_t want = std::max<size_t>(1 << 16, 2 * (bytes + 64));
+    if (h_rb) HIPCHK(hipHostFree(h_rb));
+    h_rb = nullptr;
+    HIPCHK(hipHostMalloc(&h_rb, want, hipHostMallocDefault));
+    rb_cap = want;
+    rb_off = 0;
+    return EKF_OK;
+  }
+  // queue `bytes` from device `src` for host `dst` (copied out by rb_finish)
+  int rb_add(void* dst, const void* src, size_t bytes) {
+    int rc = rb_reserve(bytes);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(static_cast<char*>(h_rb) + rb_off, src, bytes, hipMemcpyDeviceToHost, stream));
+    rb_pend.push_back({dst, rb_off, bytes});
+    rb_off += (bytes + 15) & ~size_t(15);
+    return EKF_OK;
+  }
+  // queue a rows x cols block (device pitch in bytes), packed row-major at dst
+  int rb_add_2d(void* dst, const void* src, size_t pitch, size_t row_bytes, int rows) {
+    int rc = rb_reserve(row_bytes * rows);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy2DAsync(static_cast<char*>(h_rb) + rb_off, row_bytes, src, pitch, row_bytes, rows, hipMemcpyDeviceToHost,
+                            stream));
+    rb_pend.push_back({dst, rb_off, row_bytes * rows});
+    rb_off += (row_bytes * rows + 15) & ~size_t(15);
+    return EKF_OK;
+  }
+  // one synchronisation for everything queued (+ the status words when asked for), then the pieces go to their places
+  int rb_finish(bool with_status) {
     int st[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpyAsync(st, d_status, sizeof(st), hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
+    if (with_status) { int rc = rb_add(st, d_status, sizeof(st)); if (rc) { rb_pend.clear(); rb_off = 0; return rc; } }
+    hipError_t e = hipStreamSynchronize(stream);
+    if (e == hipSuccess)
+      for (const RbPiece& p : rb_pend) memcpy(p.dst, static_cast<const char*>(h_rb) + p.off, p.bytes);
+    rb_pend.clear();
+    rb_off = 0;
+    HIPCHK(e);
+    return with_status ? eval_status(st) : EKF_OK;
+  }
+  int eval_status(const int* st) {
     if (st[0] || st[1] || st[3]) {
       HIPCHK(hipMemsetAsync(d_status, 0, 4 * sizeof(int), stream));
       if (st[3]) FAIL(EKF_ERR_DEVICE, "a bounded device-side wait gave up (fused launch)");
@@ -511,6 +558,9 @@ struct Filter : FilterBase {
     return EKF_OK;
   }
 
+  int check_status() {
+    return rb_finish(true);
+  }
   // ---- simple accessors -----------------------------------------------------------------
   int set_dt(double v) override { if (!(v > 0)) FAIL(EKF_ERR_ARG, "dT must be positive"); dT = v; return EKF_OK; }
   double get_dt() const override { return dT; }
@@ -817,8 +867,7 @@ struct Filter : FilterBase {
     if (rc) return -rc;
     k_linearity<T><<<(N + 127) / 128, 128, 0, stream>>>(mu(), S(), ld, d_pos, d_coding, N, d_cflag, d_Jy, d_Yxyz, 0);
     std::vector<unsigned char> fl(N);
-    if (hipMemcpyAsync(fl.data(), d_cflag, N, hipMemcpyDeviceToHost, stream) != hipSuccess ||
-        hipStreamSynchronize(stream) != hipSuccess) { err = "linearity flags D2H failed"; return -EKF_ERR_DEVICE; }
+    if (rb_add(fl.data(), d_cflag, N) != EKF_OK || rb_finish(false) != EKF_OK) { err = "linearity flags D2H failed"; return -EKF_ERR_DEVICE; }
     std::vector<char> rm(N, 0), cv(N, 0);
     int cnt = 0;
     for (int i = 0; i < N; ++i) {
@@ -908,8 +957,7 @@ struct Filter : FilterBase {
     HIPCHK(hipSetDevice(device));
     if (!have_motion) FAIL(EKF_ERR_STATE, "no motion Jacobian: call ekf_predict first");
     T buf[2 * 169];
-    HIPCHK(hipMemcpyAsync(buf, d_scr + SCR_FT, sizeof(buf), hipMemcpyDeviceToHost, stream));   // SCR_FT, SCR_Q adjacent
-    HIPCHK(hipStreamSynchronize(stream));
+    { int rc = rb_add(buf, d_scr + SCR_FT, sizeof(buf)); if (rc) return rc; rc = rb_finish(false); if (rc) return rc; }   // SCR_FT, SCR_Q adjacent
     for (int b = 0; b < 2; ++b) {
       T* o = static_cast<T*>(b ? Q : Ft);
       if (!o) continue;
@@ -1552,9 +1600,8 @@ struct Filter : FilterBase {
   int get_state(void* out, int off, int count) override {
     HIPCHK(hipSetDevice(device));
     if (off < 0 || count < 0 || off + count > n) FAIL(EKF_ERR_ARG, "state segment out of range");
-    if (count) HIPCHK(hipMemcpyAsync(out, mu() + off, (size_t)count * sizeof(T), hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
-    return check_status();
+    if (count) { int rc = rb_add(out, mu() + off, (size_t)count * sizeof(T)); if (rc) return rc; }
+    return rb_finish(true);                              // data and status words in one synchronisation
   }
   int set_state(const void* in, int off, int count) override {
     HIPCHK(hipSetDevice(device));
@@ -1570,13 +1617,21 @@ struct Filter : FilterBase {
       FAIL(EKF_ERR_ARG, "covariance block out of range");
     if (rows == 0 || cols == 0) return EKF_OK;
     std::vector<T> tmp((size_t)rows * cols);
-    HIPCHK(hipMemcpy2DAsync(tmp.data(), (size_t)cols * sizeof(T), S() + (size_t)r0 * ld + c0, (size_t)ld * sizeof(T),
-                            (size_t)cols * sizeof(T), rows, hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
+    int rcs = EKF_OK;
+    if (tmp.size() * sizeof(T) <= ((size_t)1 << 22)) {    // small blocks: pinned bounce, status in the same round trip
+      int rc = rb_add_2d(tmp.data(), S() + (size_t)r0 * ld + c0, (size_t)ld * sizeof(T), (size_t)cols * sizeof(T), rows);
+      if (rc) return rc;
+      rcs = rb_finish(true);
+    } else {
+      HIPCHK(hipMemcpy2DAsync(tmp.data(), (size_t)cols * sizeof(T), S() + (size_t)r0 * ld + c0, (size_t)ld * sizeof(T),
+                              (size_t)cols * sizeof(T), rows, hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+      rcs = check_status();
+    }
     T* o = static_cast<T*>(out);
     for (int r = 0; r < rows; ++r)
       for (int c = 0; c < cols; ++c) o[(size_t)c * rows + r] = tmp[(size_t)r * cols + c];
-    return check_status();
+    return rcs;
   }
   int set_sigma(const void* in, int r0, int c0, int rows, int cols) override {
     HIPCHK(hipSetDevice(device));
@@ -1610,22 +1665,21 @@ struct Filter : FilterBase {
     dim3 grid(std::min(16, (ld + 255) / 256), n_pad);
     k_check_invariants<T><<<grid, 256, 0, stream>>>(S(), ld, n, n_pad, d_out);
     unsigned int h[4];
-    HIPCHK(hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
+    { int rc = rb_add(h, d_out, sizeof(h)); if (rc) return rc; }
+    int rcs = rb_finish(true);
     float f[3];
     memcpy(f, h, sizeof(f));
     if (pad) *pad = f[0];
     if (asym) *asym = f[1];
     if (big) *big = f[2];
-    return check_status();
+    return rcs;
   }
   int feature_xyz(int index, void* xyz, void* cov) override {
     HIPCHK(hipSetDevice(device));
     if (index < 0 || index >= N) FAIL(EKF_ERR_ARG, "feature index out of range");
     k_feature_xyz<T><<<1, 64, 0, stream>>>(mu(), S(), ld, pos[index], coding[index], d_tmp);
     T o[12];
-    HIPCHK(hipMemcpyAsync(o, d_tmp, sizeof(o), hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
+    { int rc = rb_add(o, d_tmp, sizeof(o)); if (rc) return rc; rc = rb_finish(false); if (rc) return rc; }
     T* x = static_cast<T*>(xyz);
     T* c = static_cast<T*>(cov);
     if (x) for (int k = 0; k < 3; ++k) x[k] = o[k];
@@ -1688,15 +1742,12 @@ struct Filter : FilterBase {
     int rc = sync_layout();
     if (rc) return rc;
     if (!d_pts) HIPCHK(hipMalloc(&d_pts, (size_t)std::max(capN, 1) * 12 * sizeof(T)));
-    T scale = T(1);
-    if (camera_dim == 14) {
-      HIPCHK(hipMemcpyAsync(&scale, mu() + 13, sizeof(T), hipMemcpyDeviceToHost, stream));
-      HIPCHK(hipStreamSynchronize(stream));
-    }
-    k_export_points<T><<<(N + 63) / 64, 64, 0, stream>>>(mu(), S(), ld, d_pos, d_coding, N, scale, convert, d_pts);
-    HIPCHK(hipMemcpyAsync(out, d_pts, (size_t)N * 12 * sizeof(T), hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
-    return check_status();
+    const T* scale_ptr = (camera_dim == 14) ? mu() + 13 : nullptr;      // the map scale is read on the device
+    k_export_points<T><<<(N + 63) / 64, 64, 0, stream>>>(mu(), S(), ld, d_pos, d_coding, N, T(1), convert, d_pts, nullptr, 0,
+                                                        scale_ptr);
+    HIPCHK(hipGetLastError());
+    { int rcb = rb_add(out, d_pts, (size_t)N * 12 * sizeof(T)); if (rcb) return rcb; }
+    return rb_finish(true);                                             // table and status words: one synchronisation
   }
 
   // RosVSLAM::getPointsFeatures with its real_index row order and the archived patches (RosVSLAMRansac.cpp:340-418)
@@ -1711,24 +1762,29 @@ struct Filter : FilterBase {
     T* d_tab = nullptr;
     HIPCHK(hipMalloc(&d_tab, (size_t)rows * 12 * sizeof(T)));
     HIPCHK(hipMemsetAsync(d_tab, 0, (size_t)rows * 12 * sizeof(T), stream));
-    T scale = T(1);
-    if (camera_dim == 14) {
-      HIPCHK(hipMemcpyAsync(&scale, mu() + 13, sizeof(T), hipMemcpyDeviceToHost, stream));
-      HIPCHK(hipStreamSynchronize(stream));
-    }
+    const T* scale_ptr = (camera_dim == 14) ? mu() + 13 : nullptr;      // the map scale is read on the device
     const size_t na = arch_real.size();
     rc = ensure_arch_idx((size_t)N + na);
     if (rc) { hipFree(d_tab); return rc; }
     HIPCHK(hipMemcpyAsync(d_arch_idx, real_index.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, stream));
     if (na) HIPCHK(hipMemcpyAsync(d_arch_idx + N, arch_real.data(), na * sizeof(int), hipMemcpyHostToDevice, stream));
-    k_export_points<T><<<(N + 63) / 64, 64, 0, stream>>>(mu(), S(), ld, d_pos, d_coding, N, scale, 0, d_tab, d_arch_idx, rows);
+    k_export_points<T><<<(N + 63) / 64, 64, 0, stream>>>(mu(), S(), ld, d_pos, d_coding, N, T(1), 0, d_tab, d_arch_idx, rows,
+                                                        scale_ptr);
     if (na)
-      k_export_archived<T><<<((int)na * 12 + 255) / 256, 256, 0, stream>>>(d_archive, d_arch_idx + N, (int)na, scale, d_tab, rows);
-    HIPCHK(hipMemcpyAsync(out, d_tab, (size_t)rows * 12 * sizeof(T), hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
+      k_export_archived<T><<<((int)na * 12 + 255) / 256, 256, 0, stream>>>(d_archive, d_arch_idx + N, (int)na, T(1), d_tab, rows,
+                                                                          scale_ptr);
+    int rcs = EKF_OK;
+    if ((size_t)rows * 12 * sizeof(T) <= ((size_t)1 << 22)) {
+      rcs = rb_add(out, d_tab, (size_t)rows * 12 * sizeof(T));
+      if (!rcs) rcs = rb_finish(true);
+    } else {
+      HIPCHK(hipMemcpyAsync(out, d_tab, (size_t)rows * 12 * sizeof(T), hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+      rcs = check_status();
+    }
     HIPCHK(hipFree(d_tab));
     if (na > 7000) arch_real.clear();                           // :396-404: the archive is emptied once it is that long
-    return check_status();
+    return rcs;
   }
   int feature_ids(int* ri, int* nf) const override {
     for (int i = 0; i < N; ++i) { if (ri) ri[i] = real_index[i]; if (nf) nf[i] = n_find[i]; }
@@ -1749,9 +1805,9 @@ struct Filter : FilterBase {
     { int rcs = ensure_sd(); if (rcs) return rcs; }
     if (!d_ibuf) HIPCHK(hipMalloc(&d_ibuf, (size_t)std::max(capN, 1) * 3 * sizeof(int)));
     k_search_ellipses<T><<<(N + 127) / 128, 128, 0, stream>>>(d_Sd, N, sigma_size, d_ibuf);
-    HIPCHK(hipMemcpyAsync(out, d_ibuf, (size_t)N * 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
-    return EKF_OK;
+    HIPCHK(hipGetLastError());
+    { int rc = rb_add(out, d_ibuf, (size_t)N * 3 * sizeof(int)); if (rc) return rc; }
+    return rb_finish(false);
   }
 
   int ransac(const void* z, const int* idx, int M, double thr, int* counts, unsigned char* inl, int* best) override {
@@ -2601,8 +2657,7 @@ struct Filter : FilterBase {
       k_unpack_flags<T><<<dim3((mx + 255) / 256, sh_world), 256, 0, stream>>>(d_stage_recv, slot, d_cflag, tab);
     }
     std::vector<unsigned char> fl(N);
-    if (hipMemcpyAsync(fl.data(), d_cflag, N, hipMemcpyDeviceToHost, stream) != hipSuccess ||
-        hipStreamSynchronize(stream) != hipSuccess) { err = "linearity flags D2H failed"; return -EKF_ERR_DEVICE; }
+    if (rb_add(fl.data(), d_cflag, N) != EKF_OK || rb_finish(false) != EKF_OK) { err = "linearity flags D2H failed"; return -EKF_ERR_DEVICE; }
     std::vector<char> rm(N, 0), cv(N, 0);
     int cnt = 0;
     for (int i = 0; i < N; ++i) {

@@ -873,7 +873,9 @@ template <typename T>
 __global__ void k_export_points(const T* __restrict__ mu, const T* __restrict__ S, int ld,
                                 const int* __restrict__ pos, const int* __restrict__ coding, int N,
                                 T map_scale, int convert_inverse_depth, T* __restrict__ out,
-                                const int* __restrict__ row_of = nullptr, int rows = 0) {
+                                const int* __restrict__ row_of = nullptr, int rows = 0,
+                                const T* __restrict__ scale_ptr = nullptr) {
+  if (scale_ptr) map_scale = *scale_ptr;               // the scale state read where it lives: no host round trip for it
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int row = row_of ? row_of[i] : i;
@@ -930,8 +932,9 @@ __global__ void k_archive_points(const T* __restrict__ mu, const T* __restrict__
 // The archived patches written over their rows of the points table (RosVSLAMRansac.cpp:406-414): XYZ_pos * map_scale
 // and cov_4_delete.
 template <typename T>
-__global__ void k_export_archived(const T* __restrict__ arch, const int* __restrict__ row_of, int count, T map_scale,
-                                  T* __restrict__ out, int rows) {
+__global__ void k_export_archived(const T* __restrict__ arch, const int* __restrict__ row_of, int count, T map_scale_,
+                                  T* __restrict__ out, int rows, const T* __restrict__ scale_ptr = nullptr) {
+  const T map_scale = scale_ptr ? *scale_ptr : map_scale_;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = t / 12, e = t % 12;
   if (i >= count) return;
