@@ -506,7 +506,15 @@ struct Filter : FilterBase {
   std::vector<RbPiece> rb_pend;
   int rb_reserve(size_t bytes) {
     if (rb_off + bytes + 64 <= rb_cap) return EKF_OK;
-    if (!rb_pend.empty()) FAIL(EKF_ERR_STATE, "read-back buffer grown with pieces pending");
+    if (!rb_pend.empty()) {                            // pieces already queued: deliver them before the buffer moves
+      hipError_t e = hipStreamSynchronize(stream);
+      if (e == hipSuccess)
+        for (const RbPiece& p : rb_pend) memcpy(p.dst, static_cast<const char*>(h_rb) + p.off, p.bytes);
+      rb_pend.clear();
+      rb_off = 0;
+      HIPCHK(e);
+      if (bytes + 64 <= rb_cap) return EKF_OK;
+    }
     const size_t want = std::max<size_t>(1 << 16, 2 * (bytes + 64));
     if (h_rb) HIPCHK(hipHostFree(h_rb));
     h_rb = nullptr;
@@ -730,11 +738,11 @@ struct Filter : FilterBase {
                                              d_score);
     }
     HIPCHK(hipGetLastError());
-    if (z) HIPCHK(hipMemcpyAsync(z, d_zm, (size_t)N * 2 * sizeof(T), hipMemcpyDeviceToHost, stream));
-    if (found) HIPCHK(hipMemcpyAsync(found, d_found, (size_t)N, hipMemcpyDeviceToHost, stream));
-    if (score) HIPCHK(hipMemcpyAsync(score, d_score, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
-    return EKF_OK;
+    // the three results through the pinned bounce buffer: one synchronisation
+    if (z) { rc = rb_add(z, d_zm, (size_t)N * 2 * sizeof(T)); if (rc) return rc; }
+    if (found) { rc = rb_add(found, d_found, (size_t)N); if (rc) return rc; }
+    if (score) { rc = rb_add(score, d_score, (size_t)N * sizeof(float)); if (rc) return rc; }
+    return rb_finish(false);
   }
 
   // zero everything of buffer `b` outside the live n x n (up to what was ever written there)
