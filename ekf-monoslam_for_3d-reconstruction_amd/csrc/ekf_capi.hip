@@ -1870,8 +1870,8 @@ struct Filter : FilterBase {
       if (with_mask) {
         for (int k = 0; k < M; ++k) inl[k] = pmask[(size_t)k * M + b];
       } else {
-        HIPCHK(hipMemcpy2DAsync(inl, 1, d_rmask + b, (size_t)M, 1, M, hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
+        int rcf = fetch_mask_column(b, idx, M, inl);
+        if (rcf) return rcf;
       }
     }
     return EKF_OK;
@@ -2309,8 +2309,13 @@ struct Filter : FilterBase {
       return EKF_OK;
     }
     if (!sh_on) {
-      HIPCHK(hipMemcpy2DAsync(out, 1, d_rmask + sel, (size_t)M, 1, M, hipMemcpyDeviceToHost, stream));
+      // a large mask stayed on the device: its column is packed there (a strided 2-D copy of M one-byte rows takes
+      // milliseconds at M = 1000) and comes back through pinned memory
+      if (!h_gate) HIPCHK(hipHostMalloc(&h_gate, (size_t)std::max(capN, 1) + 64, hipHostMallocDefault));
+      k_pack_mask_col<<<(M + 255) / 256, 256, 0, stream>>>(d_rmask, M, sel, 0, M, static_cast<unsigned char*>(h_gate));
+      HIPCHK(hipGetLastError());
       HIPCHK(hipStreamSynchronize(stream));
+      memcpy(out, h_gate, (size_t)M);
       return EKF_OK;
     }
     const ShardTab lt = list_tab(idx, M);
