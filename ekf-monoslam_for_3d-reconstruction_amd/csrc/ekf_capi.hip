@@ -526,8 +526,10 @@ struct Filter : FilterBase {
   // queue `bytes` from device `src` for host `dst` (copied out by rb_finish)
   int rb_add(void* dst, const void* src, size_t bytes) {
     int rc = rb_reserve(bytes);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(static_cast<char*>(h_rb) + rb_off, src, bytes, hipMemcpyDeviceToHost, stream));
+    if (rc) { rb_pend.clear(); rb_off = 0; return rc; }    // (a failed batch leaves nothing queued behind)
+    hipError_t e = hipMemcpyAsync(static_cast<char*>(h_rb) + rb_off, src, bytes, hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) { rb_pend.clear(); rb_off = 0; }
+    HIPCHK(e);
     rb_pend.push_back({dst, rb_off, bytes});
     rb_off += (bytes + 15) & ~size_t(15);
     return EKF_OK;
@@ -535,9 +537,11 @@ struct Filter : FilterBase {
   // queue a rows x cols block (device pitch in bytes), packed row-major at dst
   int rb_add_2d(void* dst, const void* src, size_t pitch, size_t row_bytes, int rows) {
     int rc = rb_reserve(row_bytes * rows);
-    if (rc) return rc;
-    HIPCHK(hipMemcpy2DAsync(static_cast<char*>(h_rb) + rb_off, row_bytes, src, pitch, row_bytes, rows, hipMemcpyDeviceToHost,
-                            stream));
+    if (rc) { rb_pend.clear(); rb_off = 0; return rc; }
+    hipError_t e = hipMemcpy2DAsync(static_cast<char*>(h_rb) + rb_off, row_bytes, src, pitch, row_bytes, rows,
+                                    hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) { rb_pend.clear(); rb_off = 0; }
+    HIPCHK(e);
     rb_pend.push_back({dst, rb_off, row_bytes * rows});
     rb_off += (row_bytes * rows + 15) & ~size_t(15);
     return EKF_OK;
