@@ -32,7 +32,9 @@
 extern "C" {
 #endif
 
-#define EKF_ABI_VERSION 2
+/* 3 (round 3): + ekf_export_points_table, ekf_get_feature_ids, ekf_set_feature_meta, ekf_num_archived,
+ * EKF_OPT_FUSED_LAUNCHES; the sharded filter accepts the whole update flow; - ekf_debug_flow_trace */
+#define EKF_ABI_VERSION 3
 
 typedef struct ekf_filter ekf_filter;
 
