@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--cpu-full", action="store_true",
                     help="also time ONE frame of the dense formulation on a single thread (minutes at N = 1000; for profiles/)")
     ap.add_argument("--pipeline", type=int, default=-1, help="EKF_OPT_PIPELINE (overlap chain with solve/downdate pieces)")
+    ap.add_argument("--secondary-split-bf16", action="store_true",
+                    help="also run the secondary pass with EKF_OPT_SPLIT_BF16 (an opt-in variant; not part of the default run)")
     ap.add_argument("--split-bf16", action="store_true",
                     help="EKF_OPT_SPLIT_BF16: downdate on the bf16 matrix pipe, fp32 operands split 3 x bf16 (NOT the default "
                          "and not the headline: the line then says so in `dtype` and `config`)")
@@ -384,7 +386,8 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
         # n^2 x the real columns of every downdate launch (symmetric half); with the default pipeline the
         # first chunk's launch also carries that chunk's W update (2 (n+1)(m - c1) x its columns), counted with it.
         t_k = syrk_ms / syrk_cnt * 1e-3
-        pieces = max(1, round(syrk_cnt * sample / args.steps))
+        # launches per step: the timed launches / the steps that were timed (every `sample`-th of the K steps)
+        pieces = max(1, round(syrk_cnt / max(1, -(-args.steps // sample))))
         flop = work.get("downdate_syrk", 0.0) / syrk_cnt
         ach = flop / t_k / 1e12
         roofline = {"kernel": "downdate_syrk (k_gemm_nt_mfma, f32 MFMA 32x32x2)", "bound": "mfma",
@@ -396,6 +399,16 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
                              "serial Cholesky chain, EKF_OPT_PIPELINE; the first also carries its chunk's W update); "
                              "--pipeline 0 runs one launch" % pieces)
                             if pieces > 1 or args.pipeline != 0 else "one launch per step"}
+
+    # the whole step against the f32 MFMA peak: algorithmic flop of this formulation (SURVEY 8d / DESIGN 4: symmetric-half
+    # downdate n^2 m, triangular solve n m^2, Cholesky m^3 / 3; the O(13 n m) of W and S and the strips are < 1 %)
+    step_flop = float(n) * n * m + float(n) * m * m + float(m) ** 3 / 3.0
+    ach_step = step_flop / (ms_per_step * 1e-3) / 1e12
+    roofline_step = {"bound": "mfma" if n_feat >= 600 else "latency", "achieved": round(ach_step, 2), "peak": PEAK_F32_MFMA_TF,
+                     "unit": "TFLOP/s", "frac": round(ach_step / PEAK_F32_MFMA_TF, 4), "traffic": None,
+                     "algorithmic_flop_per_step": step_flop,
+                     "basis": "whole step: n^2 m (downdate, symmetric half) + n m^2 (V = W L^-T) + m^3 / 3 (Cholesky of S) "
+                              "flop / ms_per_step, against the f32 MFMA peak"}
 
     # HBM traffic per launch: measured by two rocprofv3 --pmc child passes of this run (live_pmc_traffic); when those are
     # not available (child of a profiler, no rocprofv3, --no-live-traffic) from the committed PMC passes, which belong to
@@ -438,6 +451,7 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
                    "frames_per_map": flt.seg, "maps": len(flt.filters)},
         "run_sane": sane, "features_visible_at_end": int(vis.sum()), "features_rho_nonpositive_at_end": int(rem.sum()),
         "roofline": roofline,
+        "roofline_step": roofline_step,
         "kernel_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()},
     }
 
@@ -528,7 +542,7 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
                 "kernel_ms_per_step": {kname: round(v, 4) for kname, (v, _) in sorted(per.items(), key=lambda kv: -kv[1][0])[:8]}}
             flt6.close()
 
-        if n_feat >= 600 and not args.split_bf16:
+        if n_feat >= 600 and not args.split_bf16 and args.secondary_split_bf16:
             # opt-in variant (NOT the headline, not the default): the covariance downdate on the bf16 matrix pipe
             # with every fp32 operand split exactly into 3 x bf16 (EKF_OPT_SPLIT_BF16; accuracy against fp64 in
             # tests/test_gpu_parity.py::test_split_bf16_downdate_is_fp32_accurate, tools/split_accuracy.py)

@@ -249,7 +249,7 @@ struct Filter : FilterBase {
     for (auto e : pool) hipEventDestroy(e);
     void* ptrs[] = {d_pos, d_coding, d_mu[0], d_mu[1], d_S[0], d_S[1], d_scr, d_h, d_Hc, d_Hf, d_Sd,
                     d_flags, d_cflag, d_Jy, d_Yxyz, d_map_src, d_map_conv, d_Y, d_W, d_V, d_Dinv, d_z, d_midx,
-                    d_status, d_tmp, d_K, d_tilemap, d_counters, d_ibuf, d_rmask, d_pts,
+                    d_status, d_tmp, d_K, d_tilemap, d_counters, d_ibuf, d_rmask, d_pts, d_tab,
                     d_frame, d_patch[0], d_patch[1], d_mpatch[0], d_mpatch[1], d_hb, d_zm, d_found, d_score, d_keep,
                     d_Vs[0], d_Vs[1], d_Vs[2], d_stage_send, d_stage_recv, d_archive, d_arch_idx, d_panel_tiles};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -561,7 +561,14 @@ struct Filter : FilterBase {
   int eval_status(const int* st) {
     if (st[0] || st[1] || st[3]) {
       HIPCHK(hipMemsetAsync(d_status, 0, 4 * sizeof(int), stream));
-      if (st[3]) FAIL(EKF_ERR_DEVICE, "a bounded device-side wait gave up (fused launch)");
+      if (st[3]) {
+        // the arrival gate of k_predict_fused was left mid-count: every launch that could still add to it has to be
+        // over before it is cleared, and the fused predict launch stays off for this filter from here on
+        HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(hipMemsetAsync(d_status + 8, 0, sizeof(int), stream));
+        opt_fused = 0;
+        FAIL(EKF_ERR_DEVICE, "a bounded device-side wait gave up (fused launch); EKF_OPT_FUSED_LAUNCHES is now off for this filter");
+      }
       if (st[1])
         FAIL(EKF_ERR_ARG, "ekf_update_device: a device-resident index is outside [0, N) or the list is not strictly "
                           "ascending (indices were clamped; the state is not meaningful)");
@@ -779,18 +786,23 @@ struct Filter : FilterBase {
     for (int i = 0; i < N; ++i)
       if (rm[i] && coding[i] != 0 && n_find[i] > 5) { ap.push_back(pos[i]); ar.push_back(real_index[i]); }
     if (ap.empty()) return EKF_OK;
+    // sharded: the 3 x 3 block of a removed feature is valid on its owner only -- gathered first, so that every rank
+    // archives the same 12 scalars (the list above is the same on every rank: host metadata is replicated)
+    int rc = shard_sync_diag_blocks();
+    if (rc) return rc;
     const size_t have = arch_real.size(), need = have + ap.size();
     if (need > arch_cap) {
       const size_t cap = std::max<size_t>(2 * need, 256);
       T* nbuf = nullptr;
       HIPCHK(hipMalloc(&nbuf, cap * 12 * sizeof(T)));
-      if (have) HIPCHK(hipMemcpyAsync(nbuf, d_archive, have * 12 * sizeof(T), hipMemcpyDeviceToDevice, stream));
-      HIPCHK(hipStreamSynchronize(stream));
+      hipError_t e1 = have ? hipMemcpyAsync(nbuf, d_archive, have * 12 * sizeof(T), hipMemcpyDeviceToDevice, stream) : hipSuccess;
+      if (e1 == hipSuccess) e1 = hipStreamSynchronize(stream);
+      if (e1 != hipSuccess) { hipFree(nbuf); HIPCHK(e1); }
       if (d_archive) HIPCHK(hipFree(d_archive));
       d_archive = nbuf;
       arch_cap = cap;
     }
-    int rc = ensure_arch_idx(ap.size());
+    rc = ensure_arch_idx(ap.size());
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(d_arch_idx, ap.data(), ap.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     k_archive_points<T><<<((int)ap.size() * 12 + 255) / 256, 256, 0, stream>>>(mu(), S(), ld, d_arch_idx, (int)ap.size(),
@@ -1689,6 +1701,7 @@ struct Filter : FilterBase {
   int feature_xyz(int index, void* xyz, void* cov) override {
     HIPCHK(hipSetDevice(device));
     if (index < 0 || index >= N) FAIL(EKF_ERR_ARG, "feature index out of range");
+    { int rcs = shard_sync_diag_blocks(); if (rcs) return rcs; }      // sharded: the owner's block of the feature (collective)
     k_feature_xyz<T><<<1, 64, 0, stream>>>(mu(), S(), ld, pos[index], coding[index], d_tmp);
     T o[12];
     { int rc = rb_add(o, d_tmp, sizeof(o)); if (rc) return rc; rc = rb_finish(false); if (rc) return rc; }
@@ -1748,12 +1761,16 @@ struct Filter : FilterBase {
   }
 
   T* d_pts = nullptr;
+  T* d_tab = nullptr;                    // table of ekf_export_points_table (grow-only)
+  size_t tab_rows_cap = 0;
   int export_points(void* out, int convert) override {
     HIPCHK(hipSetDevice(device));
     if (N == 0) return EKF_OK;
     int rc = sync_layout();
     if (rc) return rc;
     if (!d_pts) HIPCHK(hipMalloc(&d_pts, (size_t)std::max(capN, 1) * 12 * sizeof(T)));
+    rc = shard_sync_diag_blocks();                                      // sharded: every feature's own block from its owner
+    if (rc) return rc;
     const T* scale_ptr = (camera_dim == 14) ? mu() + 13 : nullptr;      // the map scale is read on the device
     k_export_points<T><<<(N + 63) / 64, 64, 0, stream>>>(mu(), S(), ld, d_pos, d_coding, N, T(1), convert, d_pts, nullptr, 0,
                                                         scale_ptr);
@@ -1771,13 +1788,22 @@ struct Filter : FilterBase {
     if (max_rows < rows) FAIL(EKF_ERR_ARG, "ekf_export_points_table: the buffer holds fewer rows than the table");
     int rc = sync_layout();
     if (rc) return rc;
-    T* d_tab = nullptr;
-    HIPCHK(hipMalloc(&d_tab, (size_t)rows * 12 * sizeof(T)));
+    rc = shard_sync_diag_blocks();                                      // sharded: every feature's own block from its owner
+    if (rc) return rc;
+    if ((size_t)rows > tab_rows_cap) {                                  // grow-only table buffer (freed with the filter)
+      HIPCHK(hipStreamSynchronize(stream));
+      if (d_tab) HIPCHK(hipFree(d_tab));
+      d_tab = nullptr;
+      tab_rows_cap = 0;
+      const size_t cap = std::max<size_t>(2 * (size_t)rows, 256);
+      HIPCHK(hipMalloc(&d_tab, cap * 12 * sizeof(T)));
+      tab_rows_cap = cap;
+    }
     HIPCHK(hipMemsetAsync(d_tab, 0, (size_t)rows * 12 * sizeof(T), stream));
     const T* scale_ptr = (camera_dim == 14) ? mu() + 13 : nullptr;      // the map scale is read on the device
     const size_t na = arch_real.size();
     rc = ensure_arch_idx((size_t)N + na);
-    if (rc) { hipFree(d_tab); return rc; }
+    if (rc) return rc;
     HIPCHK(hipMemcpyAsync(d_arch_idx, real_index.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, stream));
     if (na) HIPCHK(hipMemcpyAsync(d_arch_idx + N, arch_real.data(), na * sizeof(int), hipMemcpyHostToDevice, stream));
     k_export_points<T><<<(N + 63) / 64, 64, 0, stream>>>(mu(), S(), ld, d_pos, d_coding, N, T(1), 0, d_tab, d_arch_idx, rows,
@@ -1794,7 +1820,6 @@ struct Filter : FilterBase {
       HIPCHK(hipStreamSynchronize(stream));
       rcs = check_status();
     }
-    HIPCHK(hipFree(d_tab));
     if (na > 7000) arch_real.clear();                           // :396-404: the archive is emptied once it is that long
     return rcs;
   }
@@ -1853,10 +1878,11 @@ struct Filter : FilterBase {
     }
     // ONE read-back: counts, the camera pose and -- up to 64 KiB -- the whole inlier mask through a host-mapped pinned
     // buffer the device writes (k_pack_ransac), one synchronisation
-    if (!h_ransac) HIPCHK(hipHostMalloc(&h_ransac, (size_t)capN * sizeof(int) + 8 * sizeof(T) + kRansacMaskBytes + 64,
+    const size_t counts_bytes = ((size_t)capN * sizeof(int) + 15) / 16 * 16;   // the pose behind the counts stays 16-byte aligned
+    if (!h_ransac) HIPCHK(hipHostMalloc(&h_ransac, counts_bytes + 8 * sizeof(T) + kRansacMaskBytes + 64,
                                         hipHostMallocDefault));
     int* pc = reinterpret_cast<int*>(h_ransac);
-    T* pcam = reinterpret_cast<T*>(pc + capN);
+    T* pcam = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(h_ransac) + counts_bytes);
     unsigned char* pmask = reinterpret_cast<unsigned char*>(pcam + 8);
     const int with_mask = ((size_t)M * M <= kRansacMaskBytes) ? 1 : 0;
     k_pack_ransac<T><<<with_mask ? std::max(1, std::min(64, (M * M + 255) / 256)) : (M + 255) / 256, 256, 0, stream>>>(
@@ -2160,6 +2186,29 @@ struct Filter : FilterBase {
     rc = all_gather(slot, stream);
     if (rc) return rc;
     k_unpack_sd<T><<<dim3((4 * mx + 255) / 256, sh_world), 256, 0, stream>>>(d_stage_recv, slot, list, d_Sd, tab);
+    HIPCHK(hipGetLastError());
+    return EKF_OK;
+  }
+  // Sharded filter: the diagonal block of EVERY feature valid on this rank (a rank's Sigma holds valid rows for the camera
+  // and its own features only; the map getters and the removal archive read a feature's own 3 x 3 / 6 x 6 block).  One
+  // all-gather of 36 scalars per feature; the foreign blocks are written into the local Sigma (rows nobody else reads,
+  // which the next gather of those rows overwrites).  A COLLECTIVE: every rank makes the call.
+  int shard_sync_diag_blocks() {
+    if (!sh_on || !exchanges() || N == 0) return EKF_OK;
+    int rc = sync_layout();
+    if (rc) return rc;
+    const ShardTab tab = feature_tab();
+    int mx = 0;
+    for (int g = 0; g < sh_world; ++g) mx = std::max(mx, tab.count[g]);
+    const size_t slot = (size_t)36 * mx;
+    rc = ensure_stage(slot);
+    if (rc) return rc;
+    const int own = tab.count[sh_rank];
+    if (own > 0)
+      k_pack_diag<T><<<(36 * own + 255) / 256, 256, 0, stream>>>(S(), ld, d_pos, d_coding, tab.start[sh_rank], own, d_stage_send);
+    rc = all_gather(slot, stream);
+    if (rc) return rc;
+    k_unpack_diag<T><<<dim3((36 * mx + 255) / 256, sh_world), 256, 0, stream>>>(d_stage_recv, slot, S(), ld, d_pos, d_coding, tab);
     HIPCHK(hipGetLastError());
     return EKF_OK;
   }

@@ -120,6 +120,30 @@ __global__ void k_unpack_sd(const T* __restrict__ recv, size_t slot_elems, const
   Sd[(size_t)f * 4 + (t & 3)] = recv[(size_t)g * slot_elems + t];
 }
 
+// Diagonal blocks of Sigma (the 6 x 6 -- XYZ feature: 3 x 3, zero-padded -- block of every feature of a contiguous range):
+// what the map getters and the removal archive read of a feature's covariance (RosVSLAMRansac.cpp:177-183, 376-388,
+// vslamRansac.cpp:394-404).  Only the owner's rows of Sigma are valid, so the owners' blocks are gathered first.
+template <typename T>
+__global__ void k_pack_diag(const T* __restrict__ S, int ld, const int* __restrict__ pos, const int* __restrict__ coding,
+                            int first, int count, T* __restrict__ dst) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 36 * count) return;
+  const int f = first + t / 36, e = t % 36, a = e / 6, b = e % 6;
+  const int fs = coding[f] ? 3 : 6;
+  dst[t] = (a < fs && b < fs) ? S[(size_t)(pos[f] + a) * ld + pos[f] + b] : T(0);
+}
+template <typename T>
+__global__ void k_unpack_diag(const T* __restrict__ recv, size_t slot_elems, T* __restrict__ S, int ld,
+                              const int* __restrict__ pos, const int* __restrict__ coding, ShardTab tab) {
+  const int g = blockIdx.y;
+  if (g == tab.self) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 36 * tab.count[g]) return;
+  const int f = tab.start[g] + t / 36, e = t % 36, a = e / 6, b = e % 6;
+  const int fs = coding[f] ? 3 : 6;
+  if (a < fs && b < fs) S[(size_t)(pos[f] + a) * ld + pos[f] + b] = recv[(size_t)g * slot_elems + t];
+}
+
 // column `col` of the M x M inlier mask, rows [j0, j0 + count) -> bytes
 __global__ void k_pack_mask_col(const unsigned char* __restrict__ mask, int M, int col, int j0, int count,
                                 unsigned char* __restrict__ dst) {

@@ -362,7 +362,20 @@ typedef struct ekf_shard_info {
  * partial inlier counts are all-gathered), ekf_rescue_high_innovation and the 2x2 St blocks behind ekf_get_predictions /
  * ekf_get_search_ellipses (owner-computes, the blocks are all-gathered), ekf_innovation_covariance; under sharding their
  * measured lists must be strictly ascending.  The image side (ekf_set_frame, ekf_set_patch, ekf_find_matches) is
- * refused with EKF_ERR_UNSUPPORTED.  world = 1 needs no callback. */
+ * refused with EKF_ERR_UNSUPPORTED.  world = 1 needs no callback.
+ *
+ * COLLECTIVE CONTRACT.  On a sharded filter (world > 1) the following entry points run one or more all-gathers and are
+ * therefore COLLECTIVE: every rank must call them, with the same arguments, in the same order relative to each other --
+ * a rank that skips one, or calls them in another order, leaves the others waiting inside the collective:
+ *   ekf_predict, ekf_update, ekf_update_device, ekf_shard_update, ekf_update_two_stage, ekf_shard_rebalance,
+ *   ekf_remove_feature(s), ekf_convert_xyz_if_linear(_all) (linearity flags; the removal archive gathers the owners'
+ *   3 x 3 blocks), ekf_innovation_covariance, ekf_ransac_1point, ekf_rescue_high_innovation,
+ *   ekf_get_predictions WITH s2 and ekf_get_search_ellipses (the 2x2 St blocks; gathered once per predict, so the
+ *   first of these calls after a predict is the collective one -- make the same calls on every rank),
+ *   ekf_feature_xyz, ekf_export_points, ekf_export_points_table (round 4: a feature's covariance block is valid on
+ *   its owner only; the owners' diagonal blocks are all-gathered first, so every rank returns the same table).
+ * Local (no exchange): ekf_add_feature, ekf_get_state, ekf_get_sigma_block (valid for camera + own rows),
+ * ekf_get_predictions without s2, ekf_covariance_parameter, ekf_shard_get_info, the setters, ekf_last_error. */
 int ekf_shard_configure(ekf_filter* f, int rank, int world, ekf_allgather_fn allgather, void* ctx);
 int ekf_shard_get_info(ekf_filter* f, ekf_shard_info* out);
 /* ekf_update with z (2 M scalars) resident in device memory and the measured list on the host. */

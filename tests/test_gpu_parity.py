@@ -5,11 +5,16 @@ class of comparison (fp32, one predict + update: Sigma 2e-5, mu 5e-6, Jacobians 
 1e-12), and tests/golden/parity_bounds.json tightens each call site to 10x the error MEASURED there on the MI355X
 (profiles/r2_parity_measured.jsonl: e.g. 5e-7 .. 2e-6 on Sigma after one fp32 update, 1e-16 .. 2e-15 in fp64).
 A failing assert prints the measured value."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
 import ekf_oracle as o
 from helpers import bound, gpu_state, make_pair, oracle_cfg, relf
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -900,6 +905,51 @@ def test_largest_config_n4000_properties():
     assert np.all(np.isfinite(h)) and vis.sum() >= 0.98 * (N - 3)
 
 
+def test_n4000_matches_fp64_oracle_sketch():
+    """BASELINE configs[4] size against the ORACLE (VERDICT r3 next #1b): N = M = 4000, n = 24 014, 63 block steps, the
+    long-chain chunk plan, two frames (predict + update; the second one sees parallax, so the inverse depths move) of the
+    bench stream, fp32 with every option at its default (the map built
+    by the filter's own 4000 fp32 adds) -- against the fp64 structured oracle's result, which
+    tools/n4000_oracle_parity.py --write-golden stored as tests/golden/n4000_oracle_sketch.npz (the oracle needs ~5 min and
+    19 GB of host memory: too slow for this suite; the FULL entry-by-entry comparison of the same run is
+    profiles/r4_n4000_oracle_parity.txt, `--hip` of that script).  Compared: mu, diag(Sigma), eight full rows of Sigma
+    (camera, first / middle / last feature) and Sigma R for four seeded Gaussian vectors, whose error norm estimates the
+    Frobenius error of the whole matrix (E |D r|^2 = |D|_F^2)."""
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import n4000_oracle_parity as npar
+    g = np.load(npar.GOLDEN)
+    N = npar.N
+    _, px0, z = npar.stream()
+    f = pkg.VSlamFilter(pkg.kinect_config(), capacity_features=N)
+    f.setDt(1.0 / 30.0)
+    for (u, v) in px0:
+        assert f.addFeature((u, v)) == 1
+    for k in range(npar.FRAMES):
+        f.predict()
+        f.update(z[k].reshape(-1), np.arange(N, dtype=np.int32))
+    f.synchronize()                                         # raises if a Cholesky pivot was not positive
+    mu = f.getFullState()
+    S = f.getFullSigma()
+    pad, asym, big = f.checkInvariants()
+    f.close()
+    assert pad == 0.0 and asym == 0.0
+    t = TOL[np.float32]
+    # ceilings of two fp32 frames on a map of 4000 fp32 adds (N = 1000 measured 1.8e-6 / 3.2e-5 after its second frame)
+    assert bound("mu vs fp64 oracle", relf(mu, g["mu"]), 2 * t["mu"])
+    assert bound("diag(Sigma) vs fp64 oracle", relf(np.diag(S), g["diag"]), 5 * t["S"])
+    rows = [int(r) for r in g["rows_idx"]]
+    assert bound("eight rows of Sigma vs fp64 oracle", relf(S[rows], g["rows"]), 5 * t["S"])
+    for k, r in enumerate(rows[4:]):                        # feature rows one by one (a camera row would hide them)
+        assert bound(f"Sigma row {k + 4} of the sketch vs fp64 oracle", relf(S[r], g["rows"][k + 4]), 5 * t["S"])
+    proj = npar.blocked_matmul(S, npar.sketch_matrix(S.shape[0]))
+    assert bound("Sigma R (4 Gaussian vectors) vs fp64 oracle", relf(proj, g["proj"]), 5 * t["S"])
+    # the sketch's estimate of |Sigma_hip - Sigma_oracle|_F / |Sigma_oracle|_F
+    est = float(np.linalg.norm(proj - g["proj"]) / np.sqrt(proj.shape[1]) / float(g["fro"]))
+    assert bound("estimated rel. Frobenius error of Sigma vs fp64 oracle", est, 5 * t["S"])
+
+
 def test_split_bf16_downdate_is_fp32_accurate():
     """EKF_OPT_SPLIT_BF16 (opt-in): the downdate on the bf16 matrix pipe with 3 x bf16 operands.  Both the exact
     fp32 path and the split path are measured against the fp64 oracle on the same inputs: the split path has
@@ -934,16 +984,32 @@ def test_split_bf16_downdate_is_fp32_accurate():
 
 
 # ---------------------------------------------------------------------------------------------
-# Oracle parity at the HEADLINE size through the production launch structure (VERDICT r2 next #1a):
+# Oracle parity at the HEADLINE size through the production launch structure (VERDICT r2 next #1a, r3 next #1a):
 # N = M = 1000, n = 6014, fp32, default options -- 16 block steps in three chunks, the fused first launch, half
-# tiles, the CU-masked second stream -- against the fp64 structured oracle on the same inputs, two frames.
+# tiles, the CU-masked second stream -- against the fp64 structured oracle on the same inputs, TEN frames, with the
+# fp32 structured oracle run beside it from the same start as the yardstick (tolerances are calibrated
+# against the fp32-oracle-vs-fp64-oracle gap).
 # ---------------------------------------------------------------------------------------------
+N1000_FRAMES = 10
+
+
 def test_n1000_default_pipeline_matches_fp64_oracle():
+    from threadpoolctl import threadpool_limits
     from __graft_entry__ import load_package
     pkg = load_package()
-    from helpers import n1000_oracle
-    N, frames = 1000, 2
-    px0, z, states = n1000_oracle(frames)
+    from ekf_monoslam_amd import synthetic
+    import helpers
+    import oracle_worker
+    N, frames = 1000, N1000_FRAMES
+    # z rounded to fp32 once: the fp64 oracle, the fp32 oracle and the HIP filter read the SAME numbers
+    px0, z = synthetic.measurement_stream(pkg.kinect_config(), N, frames, sigma_px=0.5, dtype=np.float32)
+    refs = {}
+    for T in (np.float64, np.float32):
+        r = o.StructuredFilter(o.Config.kinect(), T)
+        r.dT = 1.0 / 30.0
+        assert r.add_features(px0) == N
+        refs[T] = r
+    ref64, ref32 = refs[np.float64], refs[np.float32]
     f = pkg.VSlamFilter(pkg.kinect_config(), capacity_features=N)          # fp32, every option at its default
     f.setDt(1.0 / 30.0)
     for (u, v) in px0:
@@ -951,22 +1017,49 @@ def test_n1000_default_pipeline_matches_fp64_oracle():
     f.synchronize()
     # the HIP filter built its map with its OWN fp32 add-feature path: that map against the oracle's
     mu, S = gpu_state(f)
-    assert bound("map after 1000 adds: mu", relf(mu, states[0][0]), TOL[np.float32]["mu"])
-    assert bound("map after 1000 adds: Sigma", relf(S, states[0][1]), TOL[np.float32]["S"])
-    idx = np.arange(N, dtype=np.int32)
+    assert bound("map after 1000 adds: mu", relf(mu, ref64.mu), TOL[np.float32]["mu"])
+    assert bound("map after 1000 adds: Sigma", relf(S, ref64.Sigma), TOL[np.float32]["S"])
+    states = [(ref64.mu.copy(), ref64.Sigma.copy())]
+    idx = list(range(N))
+    idx_g = np.arange(N, dtype=np.int32)
+    limiter = threadpool_limits(limits=16)
+    rows = []
     for k in range(frames):
+        for r in (ref64, ref32):
+            oracle_worker.predict_no_St(r)                # St is recomputed by the update (vR.cpp:1268)
+            assert len(r.visible_indices()) == N         # the stream keeps every feature in view
+            r.update(z[k].reshape(-1).astype(r.T), idx)
         f.predict()
-        f.update(z[k].reshape(-1).astype(np.float32), idx)
+        f.update(z[k].reshape(-1), idx_g)
         f.synchronize()
         mu, S = gpu_state(f)
-        # ceilings: one fp32 predict + update on top of a map built by 1000 fp32 adds; the second frame carries the
-        # first one's rounding (parity_bounds.json holds each site to 10 x what the MI355X measured)
-        assert bound(f"frame {k}: mu vs fp64 oracle", relf(mu, states[k + 1][0]), (k + 1) * TOL[np.float32]["mu"])
-        assert bound(f"frame {k}: Sigma vs fp64 oracle", relf(S, states[k + 1][1]), (k + 1) * 2.5 * TOL[np.float32]["S"])
+        if k < 2:                                        # shared with the sharded N = 1000 tests (helpers.n1000_oracle)
+            states.append((ref64.mu.copy(), ref64.Sigma.copy()))
+            if k == 1:
+                helpers._N1000_ORACLE[2] = (px0, z[:2].astype(np.float64), states)
+        e_mu, e_S = relf(mu, ref64.mu), relf(S, ref64.Sigma)
+        e_Sf = relf(S[14:, 14:], ref64.Sigma[14:, 14:])
+        y_mu, y_S = relf(ref32.mu, ref64.mu), relf(ref32.Sigma, ref64.Sigma)      # the fp32 ORACLE against the truth
+        g_mu, g_S = relf(mu, ref32.mu), relf(S, ref32.Sigma)
+        rows.append((k, e_mu, e_S, y_mu, y_S, g_mu, g_S))
+        print(f"N=1000 frame {k}: HIP-o64 mu {e_mu:.2e} Sigma {e_S:.2e} | o32-o64 mu {y_mu:.2e} Sigma {y_S:.2e} | "
+              f"HIP-o32 mu {g_mu:.2e} Sigma {g_S:.2e}", flush=True)
+        # ceilings: one fp32 predict + update on top of a map built by 1000 fp32 adds; every later frame carries the
+        # rounding of the frames before it (measured growth: profiles/r4_parity_measured.jsonl; parity_bounds.json
+        # holds each site to 10 x what the MI355X measured)
+        c = min(k + 1, 4)
+        assert bound(f"frame {k}: mu vs fp64 oracle", e_mu, c * TOL[np.float32]["mu"])
+        assert bound(f"frame {k}: Sigma vs fp64 oracle", e_S, c * 2.5 * TOL[np.float32]["S"])
         assert np.array_equal(S, S.T)                    # exactly symmetric
         # the feature block alone (the camera block is 1e3 larger in norm and would hide an error there)
-        assert bound(f"frame {k}: Sigma[features] vs fp64 oracle", relf(S[14:, 14:], states[k + 1][1][14:, 14:]),
-                     (k + 1) * 2.5 * TOL[np.float32]["S"])
+        assert bound(f"frame {k}: Sigma[features] vs fp64 oracle", e_Sf, c * 2.5 * TOL[np.float32]["S"])
+        # the yardstick: the HIP fp32 path is no farther from the fp64 truth than the reference's fp32 formulation
+        # (1.5 x, + the single-frame tolerance), and its distance from the fp32 oracle is explained by that oracle's own
+        assert e_S <= 1.5 * y_S + TOL[np.float32]["S"], rows[-1]
+        assert e_mu <= 1.5 * y_mu + TOL[np.float32]["mu"], rows[-1]
+        assert g_S <= 1.5 * y_S + c * 2.5 * TOL[np.float32]["S"], rows[-1]
+        assert g_mu <= 1.5 * y_mu + c * TOL[np.float32]["mu"], rows[-1]
+    limiter.restore_original_limits()
     pad, asym, big = f.checkInvariants()
     assert pad == 0.0 and asym == 0.0
 

@@ -153,9 +153,10 @@ def _cpu_worker(rank, world, port, n_feat, frames, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_feat", [(2, 9), (4, 14), (4, 3)])
+@pytest.mark.parametrize("world,n_feat", [(2, 9), (4, 14), (4, 3), (8, 24), (8, 5)])
 def test_shard_protocol_matches_unsharded_oracle_gloo(world, n_feat):
-    """Uneven partitions (9 over 2, 14 over 4, 3 features over 4 ranks: an empty rank), subsets, plane rows, XYZ
+    """Uneven partitions (9 over 2, 14 over 4, 3 features over 4 ranks: an empty rank; world 8 = the node BASELINE
+    configs[3] / [4] name: 24 features, and 5 features over 8 ranks: three empty ranks), subsets, plane rows, XYZ
     conversions, removals and additions, re-balance: every rank's rows must equal the unsharded oracle."""
     frames = 7
     ref = cpu_scenario(lambda f: (PlainOracle(f), f), n_feat, frames)
@@ -418,10 +419,15 @@ def _gpu_flow_worker(rank, world, port, n_feat, dtype_name, out):
     flt = _mk_hip(pkg, n_feat, capacity=n_feat + 8, dtype=dtype)
     sharded.configure(flt, rank, world)
     ref = o.build_scenario(o.StructuredFilter, o.Config.kinect(), n_feat, dtype)
+    # fp32 runs: the fp64 oracle beside the fp32 one, on the same measurements and the same inlier / rescue decisions --
+    # the truth the fp32 answers are measured against (VERDICT r3 next #1c: is 4.8e-5 on mu the HIP path or the oracle?)
+    ref64 = o.build_scenario(o.StructuredFilter, o.Config.kinect(), n_feat, np.float64) if dtype == np.float32 else None
     res = {}
     # frame 1: the pieces one by one
     ref.predict()
     flt.predict()
+    if ref64 is not None:
+        ref64.predict()
     vis = ref.visible_indices()
     z = o.synthetic_measurements(ref, vis, sigma=1.0).reshape(-1, 2)
     z[5] += 7.0                                          # outside 2 sigma_px of the prediction, inside a wide chi2 gate
@@ -442,6 +448,10 @@ def _gpu_flow_worker(rank, world, port, n_feat, dtype_name, out):
     li = [vis[k] for k in range(len(vis)) if inl[k]]
     ref.update(z[inl].reshape(-1), li)
     flt.update(z[inl].reshape(-1), li)
+    if ref64 is not None:
+        assert ref64.visible_indices() == vis
+        mu_before64 = ref64.mu.copy()
+        ref64.update(z[inl].reshape(-1).astype(np.float64), li)
     rest = [vis[k] for k in range(len(vis)) if not inl[k]]
     hi_ref, chi2 = o.rescue_high_innovation(ref, mu_before, z[~inl], rest, return_chi2=True)
     thr = float(np.sqrt(chi2[rest.index(vis[5])] * chi2[rest.index(vis[9])]))
@@ -451,6 +461,10 @@ def _gpu_flow_worker(rank, world, port, n_feat, dtype_name, out):
     sel = [rest[k] for k in range(len(rest)) if hi[k]]
     zz = z[~inl][np.asarray(hi, bool)].reshape(-1)
     ref.update(zz, sel)
+    if ref64 is not None:
+        hi64 = o.rescue_high_innovation(ref64, mu_before64, z[~inl].astype(np.float64), rest, threshold=thr)
+        res["decisions64"] = list(map(bool, hi64)) == list(map(bool, hi_ref))
+        ref64.update(zz.astype(np.float64), sel)
     # (device-resident list under sharding: the same update through ekf_update_device)
     d_z = torch.from_numpy(np.ascontiguousarray(zz, dtype)).cuda()
     d_i = torch.from_numpy(np.asarray(sel, np.int32)).cuda()
@@ -465,12 +479,22 @@ def _gpu_flow_worker(rank, world, port, n_feat, dtype_name, out):
         li_r, hi_r, drawn_r = o.update_two_stage(ref, z, vis, plane=(k == 1), seed=(0 if k == 0 else 77))
         li_g, hi_g, drawn_g = flt.updateTwoStage(z, vis, plane_constraint=(k == 1), seed=(0 if k == 0 else 77))
         res[f"two_stage_{k}"] = bool(np.array_equal(li_r, li_g) and np.array_equal(hi_r, hi_g) and drawn_r == drawn_g)
+        if ref64 is not None:
+            ref64.predict()
+            li_d, hi_d, drawn_d = o.update_two_stage(ref64, z.astype(np.float64), vis, plane=(k == 1), seed=(0 if k == 0 else 77))
+            res["decisions64"] = bool(res["decisions64"] and np.array_equal(li_r, li_d) and np.array_equal(hi_r, hi_d)
+                                      and drawn_r == drawn_d)
     flt.synchronize()
     info = sharded.shard_info(flt)
     rows = np.r_[0:14, info.row_begin:info.row_end]
     S = flt.getFullSigma()
     res["mu"] = relf(flt.getFullState(), ref.mu)
     res["Sigma"] = relf(S[rows], ref.Sigma[rows])
+    if ref64 is not None:
+        res["mu64"] = relf(flt.getFullState(), ref64.mu)
+        res["Sigma64"] = relf(S[rows], ref64.Sigma[rows])
+        res["o32_mu64"] = relf(ref.mu, ref64.mu)                  # the fp32 ORACLE against the same truth
+        res["o32_Sigma64"] = relf(ref.Sigma[rows], ref64.Sigma[rows])
     res["n_find"] = bool(np.array_equal(flt.featureIds()[1], [ft.n_find for ft in ref.features]))
     try:
         flt.setFrame(np.zeros((240, 320), np.uint8))
@@ -502,6 +526,18 @@ def test_hip_shard_update_flow_three_ranks_vs_oracle(dtype):
         assert bound("rank St vs oracle", r["St"], 2e-5 if f32 else 1e-10)
         assert bound("rank mu vs oracle", r["mu"], 5e-5 if f32 else 1e-11)
         assert bound("rank Sigma rows vs oracle", r["Sigma"], 2e-3 if f32 else 1e-9)
+        if f32:
+            # Against the fp64 oracle run beside the fp32 one (same measurements, same inlier / rescue decisions): the
+            # three-frame flow with 7 / 9 / 60 px outliers leaves the HIP fp32 path at the accuracy of every other
+            # fp32 site; what the line above measures is the fp32 ORACLE's distance from the truth (explicit inverse,
+            # (I - K H) Sigma), which the yardstick lines state
+            assert r["decisions64"], (rank, r)
+            print(f"flow fp32 rank {rank}: HIP-o64 mu {r['mu64']:.2e} Sigma {r['Sigma64']:.2e}; o32-o64 mu "
+                  f"{r['o32_mu64']:.2e} Sigma {r['o32_Sigma64']:.2e}; HIP-o32 mu {r['mu']:.2e} Sigma {r['Sigma']:.2e}")
+            assert bound("rank mu vs fp64 oracle", r["mu64"], 2e-5)
+            assert bound("rank Sigma rows vs fp64 oracle", r["Sigma64"], 5e-4)
+            assert r["mu"] <= 1.5 * r["o32_mu64"] + 2e-5, (rank, r)
+            assert r["Sigma"] <= 1.5 * r["o32_Sigma64"] + 5e-4, (rank, r)
 
 
 @pytest.mark.gpu
@@ -521,6 +557,36 @@ def test_rccl_smoke_script_rehearsal_over_gloo(world):
                        capture_output=True, text=True, timeout=600, env=env)
     lines = [l for l in (r.stdout + r.stderr).splitlines() if l.startswith("[rccl_smoke]")]
     assert r.returncode == 0 and len(lines) == 2 and all(l.endswith("OK") for l in lines), (r.returncode, lines, r.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_command_rehearsal_over_gloo():
+    """The exact command a SCALE driver runs for N = 2 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 --steps 3 --warmup 1` -- with the two ranks sharing the
+    one GPU of the box and the collectives over gloo (EKF_BENCH_BACKEND; on a node the same code runs over RCCL):
+    BASELINE configs[3] at full size (N = 1000), rank 0 prints ONE JSON line with the contract's keys, a finite state
+    and the time of every all-gather (VERDICT r3 next #1e: the sharded downdate was rewritten after the last rehearsal)."""
+    import json
+    import subprocess
+    env = dict(os.environ, EKF_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 2 and doc["steps"] == 3 and doc["warmup"] == 1 and doc["run_sane"] is True
+    assert doc["unit"] == "updates/s" and doc["value"] > 0 and doc["higher_is_better"] is True
+    assert abs(doc["value"] * doc["ms_per_step"] * 1e-3 - 1.0) < 1e-2          # value = steps / the max-over-ranks time
+    assert doc["config"]["features"] == 1000 and doc["config"]["backend"] == "gloo" and doc["scaling"] == "strong"
+    ag = doc["allgather_ms_per_step"]
+    assert {"H", "S", "V"} <= set(ag) and all(v > 0 for v in ag.values()), ag
+    assert doc["jacobian_innovation_shard_ms"] > 0 and doc["roofline"]["frac"] > 0
+    r0, r1 = doc["rank0_rows"]
+    assert r0 == 14 and 14 < r1 < 14 + 6 * 1000                           # rank 0 owns the first part of the rows only
 
 
 # BASELINE configs[4]: N = 4000, fp32, dynamic add / delete-feature covariance resize every 50 frames

@@ -1,0 +1,138 @@
+"""BASELINE configs[4] size against the ORACLE (VERDICT r3 next #1b): N = M = 4000 inverse-depth features, n = 24 014,
+63 block steps of the Cholesky chain, two frames (predict + update) of the bench stream.
+
+    python tools/n4000_oracle_parity.py --write-golden      (CPU only, ~5 min, ~19 GB of host memory)
+        the fp64 structured oracle (features through the batched add, predict, update over all 4000 features;
+        vslamRansac.cpp:309-371, 451-603, 1245-1284) -> tests/golden/n4000_oracle_sketch.npz: mu, diag(Sigma), a few full
+        rows of Sigma, Sigma R for 4 seeded Gaussian vectors R (E |D r|^2 = |D|_F^2: a sketch of the Frobenius error of the
+        whole 2.3 GB matrix in 0.8 MB) and the norms -- what tests/test_gpu_parity.py::test_n4000_matches_fp64_oracle_sketch
+        compares the HIP filter with on the GPU box without running the oracle there.
+    python tools/n4000_oracle_parity.py --hip               (GPU box)
+        the same oracle run next to the HIP filter (its own 4000 fp32 adds, default options), FULL comparison of mu and of
+        every entry of Sigma (relative Frobenius error, feature block alone too), and the sketch figures beside them so
+        the sketch can be judged against the truth; prints one JSON line (profiles/r4_n4000_oracle_parity.txt).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+N = 4000
+FRAMES = 2                # frame 0: camera at the anchors (depth unobservable: rho rows untouched); frame 1: parallax
+# camera r_x, q_x, v_x, scale; theta of feature 0, phi and rho of the middle feature, theta of the last one
+ROWS = [0, 4, 7, 13, 14 + 3, 14 + 6 * 1999 + 4, 14 + 6 * 1999 + 5, 14 + 6 * 3999 + 3]
+SKETCH_SEED, SKETCH_COLS = 4321, 4
+GOLDEN = os.path.join(ROOT, "tests", "golden", "n4000_oracle_sketch.npz")
+
+
+def stream():
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from ekf_monoslam_amd import synthetic
+    px0, z = synthetic.measurement_stream(pkg.kinect_config(), N, FRAMES, sigma_px=0.5, dtype=np.float32)
+    return pkg, px0, z
+
+
+def run_oracle(px0, z):
+    import ekf_oracle as o
+    import oracle_worker
+    t0 = time.time()
+    ref = o.StructuredFilter(o.Config.kinect(), np.float64)
+    ref.dT = 1.0 / 30.0
+    assert ref.add_features(px0) == N
+    t1 = time.time()
+    for k in range(FRAMES):
+        oracle_worker.predict_no_St(ref)                  # St is recomputed by the update (vR.cpp:1268)
+        assert len(ref.visible_indices()) == N
+        ref.update(z[k].reshape(-1).astype(np.float64), list(range(N)))
+        ref.Kt = ref.St = None
+    print(f"oracle: adds {t1 - t0:.0f} s, {FRAMES} x (predict + update) {time.time() - t1:.0f} s", flush=True)
+    ref.Kt = ref.St = None
+    return ref
+
+
+def sketch_matrix(n):
+    return np.random.default_rng(SKETCH_SEED).standard_normal((n, SKETCH_COLS))
+
+
+def blocked_matmul(S, R, block=2048):
+    out = np.empty((S.shape[0], R.shape[1]))
+    for r in range(0, S.shape[0], block):
+        out[r:r + block] = S[r:r + block].astype(np.float64) @ R
+    return out
+
+
+def fro_diff(A, B, block=2048, r0=0):
+    """|A - B|_F and |B|_F over rows / columns r0.. without a second copy of the matrices."""
+    d2 = b2 = 0.0
+    for r in range(r0, A.shape[0], block):
+        a = A[r:r + block, r0:].astype(np.float64)
+        b = B[r:r + block, r0:].astype(np.float64)
+        d2 += float(np.sum((a - b) ** 2))
+        b2 += float(np.sum(b ** 2))
+    return np.sqrt(d2), np.sqrt(b2)
+
+
+def sketch_of(S, mu):
+    R = sketch_matrix(S.shape[0])
+    return {"mu": np.asarray(mu, np.float64), "diag": np.diag(S).astype(np.float64).copy(),
+            "rows_idx": np.asarray(ROWS), "rows": S[ROWS].astype(np.float64),
+            "proj": blocked_matmul(S, R)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--write-golden", action="store_true")
+    ap.add_argument("--hip", action="store_true")
+    args = ap.parse_args()
+    pkg, px0, z = stream()
+    if args.write_golden:
+        ref = run_oracle(px0, z)
+        sk = sketch_of(ref.Sigma, ref.mu)
+        _, fro = fro_diff(ref.Sigma, ref.Sigma)
+        _, fro_f = fro_diff(ref.Sigma, ref.Sigma, r0=14)
+        np.savez_compressed(GOLDEN, fro=fro, fro_features=fro_f, sketch_seed=SKETCH_SEED, **sk)
+        print(f"wrote {GOLDEN}: {os.path.getsize(GOLDEN) / 1e6:.2f} MB, |Sigma|_F {fro:.6e}, features {fro_f:.6e}")
+        return
+    if args.hip:
+        f = pkg.VSlamFilter(pkg.kinect_config(), capacity_features=N)       # fp32, every option at its default
+        f.setDt(1.0 / 30.0)
+        for (u, v) in px0:
+            assert f.addFeature((u, v)) == 1
+        for k in range(FRAMES):
+            f.predict()
+            f.update(z[k].reshape(-1), np.arange(N, dtype=np.int32))
+        f.synchronize()
+        mu = f.getFullState()
+        S = f.getFullSigma()
+        f.close()
+        assert np.array_equal(S, S.T)
+        ref = run_oracle(px0, z)
+        d, b = fro_diff(S, ref.Sigma)
+        df, bf = fro_diff(S, ref.Sigma, r0=14)
+        R = sketch_matrix(S.shape[0])
+        pr, ps = blocked_matmul(ref.Sigma, R), blocked_matmul(S, R)
+        out = {"what": "N = M = 4000 (n = 24014), fp32 HIP filter (own adds, default options) vs fp64 structured oracle, two frames of predict + update",
+               "rel_mu": float(np.linalg.norm(mu - ref.mu) / np.linalg.norm(ref.mu)),
+               "rel_Sigma_fro": d / b, "rel_Sigma_features_fro": df / bf,
+               "sketch_rel_Sigma": float(np.linalg.norm(ps - pr) / np.linalg.norm(pr)),
+               "sketch_estimate_of_rel_Sigma_fro": float(np.linalg.norm(ps - pr) / np.sqrt(SKETCH_COLS) / b),
+               "rel_rows": float(np.linalg.norm(S[ROWS] - ref.Sigma[ROWS]) / np.linalg.norm(ref.Sigma[ROWS])),
+               "rel_diag": float(np.linalg.norm(np.diag(S) - np.diag(ref.Sigma)) / np.linalg.norm(np.diag(ref.Sigma)))}
+        if os.path.exists(GOLDEN):
+            g = np.load(GOLDEN)
+            out["golden_matches_this_oracle_run"] = bool(np.allclose(g["mu"], ref.mu, rtol=1e-9, atol=0) and
+                                                         np.allclose(g["proj"], pr, rtol=1e-8, atol=1e-12))
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

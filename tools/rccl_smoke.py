@@ -6,7 +6,8 @@
 (G = 2 .. 8, one rank per GPU; nothing touches a GPU before the rank has picked its device from LOCAL_RANK.)
 Every rank builds the same N-feature map, switches it to row-panel sharding over torch.distributed (backend "nccl" =
 RCCL over xGMI) and runs `frames` frames of predict + update -- all features measured, then a measured subset with the
-plane rows, a removal / addition, a conversion pass and the two-stage update of the reference's update() flow.  Every rank
+plane rows, a removal / addition, a conversion pass, the two-stage update of the reference's update() flow and the map
+export (points table with archived patches, per-feature XYZ getters: every rank must return the OWNERS' numbers).  Every rank
 ALSO runs the plain single-GPU filter on the same calls and compares its camera rows + own rows of Sigma and the
 replicated state: in fp64 (bound 1e-8: the protocol is exact up to the order of sums) and in fp32 (bound 5e-3: the two
 paths may cut S into different column chunks, and an fp32 filter amplifies rounding differences of 1e-7 to 1e-4 .. 1e-3
@@ -107,6 +108,33 @@ def run(args, pkg, sharded, synthetic, cfg, N, dtype, tol, rank, world, dev, tor
         worst = max(worst, e_S, 10 * e_mu, float(pad))       # also after a conversion / removal has shrunk n
         print(f"[rccl_smoke rank {rank}/{world} {np.dtype(dtype).name}] frame {k}: features {info.f_begin}..{info.f_end} rows {info.row_begin}..{info.row_end} "
               f"rel|mu| {e_mu:.2e} rel|Sigma rows| {e_S:.2e} rebalances {info.rebalances}", flush=True)
+    # the map export under sharding (a feature's covariance block is valid on its owner only: the owners' diagonal blocks
+    # are gathered inside these calls): removal of XYZ features that were found often enough to be archived
+    # (vslamRansac.cpp:394-404), then the points table of getPointsFeatures and the per-feature getters on EVERY rank
+    # against the plain path -- ranks that do not own a feature must return its owner's numbers
+    lay = plain.featureLayout()
+    xyz = [i for i in range(plain.numOfFeatures()) if lay[1][i] != 0]
+    if 'export' not in os.environ.get('SMOKE_SKIP', ''):
+        for f in (plain, shd):
+            for i in range(plain.numOfFeatures()):
+                f.setFeatureMeta(i, n_find=9)
+        gone = [xyz[0], xyz[len(xyz) // 2], xyz[-1]] if len(xyz) >= 6 else []
+        for f in (plain, shd):
+            if gone:
+                f.removeFeatures(sorted(set(gone)))
+        assert plain.numArchived() == shd.numArchived() == len(set(gone))
+        tp, ts = plain.getPointsTable(), shd.getPointsTable()
+        pp, ps = plain.getPointsFeatures(True), shd.getPointsFeatures(True)
+        last = plain.numOfFeatures() - 1
+        fx = [np.concatenate([np.ravel(a) for a in f.featureXYZ(i)]) for f in (plain, shd) for i in (0, last)]
+        def rel(a, b):                                       # positions and covariances on their own scales
+            return max(float(np.abs(a[..., :3] - b[..., :3]).max()) / max(float(np.abs(b[..., :3]).max()), 1e-300),
+                       float(np.abs(a[..., 3:] - b[..., 3:]).max()) / max(float(np.abs(b[..., 3:]).max()), 1e-300))
+        e_tab, e_pts = rel(ts, tp), rel(ps, pp)
+        e_fx = max(rel(fx[2], fx[0]), rel(fx[3], fx[1]))
+        worst = max(worst, e_tab, e_pts, e_fx)
+        print(f"[rccl_smoke rank {rank}/{world} {np.dtype(dtype).name}] map export: {len(xyz)} XYZ features, {len(set(gone))} archived, "
+              f"table {tp.shape[0]} rows max|diff| {e_tab:.2e}, points {e_pts:.2e}, featureXYZ {e_fx:.2e}", flush=True)
     t = torch.tensor([worst], dtype=torch.float64, device=(f"cuda:{dev}" if args.backend == "nccl" else "cpu"))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ok = bool(t.item() < tol) and bool(np.isfinite(t.item()))
