@@ -11,7 +11,7 @@ HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "ekf_monoslam.h")
 
 EKF_F32, EKF_F64 = 0, 1
 EKF_OPT_PROPAGATE_STREAMING, EKF_OPT_USE_MFMA, EKF_OPT_PROFILE, EKF_OPT_PIPELINE = 0, 1, 2, 3
-EKF_OPT_SPLIT_BF16, EKF_OPT_FEATURE_NOISE, EKF_OPT_FUSED_LAUNCHES = 4, 5, 6
+EKF_OPT_SPLIT_BF16, EKF_OPT_FEATURE_NOISE, EKF_OPT_FUSED_LAUNCHES, EKF_OPT_W_RECOMPUTE = 4, 5, 6, 7
 STATUS_NAMES = {0: "EKF_OK", 1: "EKF_ERR_ARG", 2: "EKF_ERR_CAPACITY", 3: "EKF_ERR_DEVICE",
                 4: "EKF_ERR_STATE", 5: "EKF_ERR_NUMERIC", 6: "EKF_ERR_UNSUPPORTED"}
 

@@ -218,6 +218,7 @@ struct Filter : FilterBase {
     return kIsF32 && opt_mfma && opt_solve_s2 && (opt_solve_s2 > 1 || (width / 128) * (npad_live / 64) <= 2 * num_cus);   // (2: always, for A/B runs)
   }
   int opt_fused = 1;                                    // EKF_OPT_FUSED_LAUNCHES: k_predict_fused, k_solve_state_oneblock, k_update_oneblock_small
+  int opt_wrecompute = 1;                               // EKF_OPT_W_RECOMPUTE / EKF_W_RECOMPUTE: next chunk's W re-evaluated from the downdated Sigma
   int opt_fuse_wu = 1;                                  // EKF_FUSE_WU: 0 never, 1 every overlapped chunk but the one before the last, 2 every overlapped chunk
   int env_chunks[8] = {}, env_nchunks = 0;               // EKF_CHUNKS="5,10,14,16": tuning knob (block steps)
   int opt_pipeline = -1;                                 // -1 auto: on when the chain has >= 8 block steps
@@ -409,6 +410,7 @@ struct Filter : FilterBase {
         HIPCHK(hipStreamCreateWithFlags(&stream_c, hipStreamNonBlocking));
       }
       if (const char* e = getenv("EKF_FUSE_WU")) opt_fuse_wu = atoi(e);
+      if (const char* e = getenv("EKF_W_RECOMPUTE")) opt_wrecompute = atoi(e) ? 1 : 0;   // = EKF_OPT_W_RECOMPUTE, for A/B runs
       if (const char* e = getenv("EKF_SOLVE_S2")) opt_solve_s2 = atoi(e);
       if (const char* e = getenv("EKF_FUSED_LAUNCHES")) opt_fused = atoi(e) ? 1 : 0;   // = EKF_OPT_FUSED_LAUNCHES, for A/B runs
       if (const char* e = getenv("EKF_PANEL_DIRECT")) opt_panel_direct = atoi(e);
@@ -600,6 +602,7 @@ struct Filter : FilterBase {
       case EKF_OPT_SPLIT_BF16: opt_split_bf16 = v ? 1 : 0; return EKF_OK;
       case EKF_OPT_FEATURE_NOISE: opt_feature_noise = (v > 0) ? 1e-12 * v : 0.0; return EKF_OK;
       case EKF_OPT_FUSED_LAUNCHES: opt_fused = v ? 1 : 0; return EKF_OK;
+      case EKF_OPT_W_RECOMPUTE: opt_wrecompute = v ? 1 : 0; return EKF_OK;
       default: FAIL(EKF_ERR_ARG, "unknown option");
     }
   }
@@ -1183,7 +1186,9 @@ struct Filter : FilterBase {
       // Long chains (>= 32 steps; round 3, tools/knob_ab.py: 32 steps 6/16 -> 4/14: -1 %, 63 steps 12/32 -> 5/25: -2.6 %): the chain
       // is hidden there whatever the plan, so the first two chunks shrink in proportion -- less exposed start-up, and a
       // wider last chunk, whose downdate has every CU
-      static const int kEnd16[3] = {3, 8, 16};
+      // round 4 (EKF_OPT_W_RECOMPUTE: no W update, the chain as fast as the second stream): 3 / 7 / 16 -- the last chunk's
+      // downdate has every CU and the largest K (tools/knob_ab.py: 1.169 ms against 1.187 with 3 / 8 / 16, 1.216 with 3 / 6)
+      static const int kEnd16[3] = {3, 7, 16};
       int k = 0, prev = 0;
       for (int g = 0; g < 3; ++g) {
         int e = (g == 2) ? nsteps : (nsteps * kEnd16[g] + 8) / 16;
@@ -1234,6 +1239,13 @@ struct Filter : FilterBase {
         dim3 grid((m_pad / 2 + 255) / 256, (n + RB - 1) / RB + extra);
         k_sigma_ht<T, RB><<<grid, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, ip, M, plane, d_W, ldy,
                                                   m_pad, 0, n, N, zq, d_h, mu(), nuq, d_counters, d_status, d_scr + SCR_QOLD);
+      } else if constexpr (kIsF32) {
+        // 128 slots x 8 rows per workgroup, the row segments staged through LDS (runs of neighbouring inverse-depth
+        // features; other stretches of the list take k_sigma_ht's path inside the same launch): bit-identical sums
+        constexpr int RB = 8;
+        dim3 grid((m_pad / 2 + 127) / 128, (n + RB - 1) / RB + extra);
+        k_sigma_ht_fast<RB><<<grid, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, ip, M, plane, d_W, ldy, m_pad, N,
+                                                      0, 0, zq, d_h, mu(), nuq, d_counters, d_status, d_scr + SCR_QOLD);
       } else {
         constexpr int RB = 32;
         dim3 grid((m_pad / 2 + 255) / 256, (n + RB - 1) / RB + extra);
@@ -1376,6 +1388,7 @@ struct Filter : FilterBase {
     if constexpr (kIsF32)
       oneblock = opt_fused && opt_mfma && nchunks == 1 && m_pad == 128 && nb == 128 && !prof_on(KID_SOLVE) &&
                  !prof_on(KID_STATE_UPDATE) && !prof_on(KID_CHOL_PANEL);
+    const int* ip_list = cur_midx ? cur_midx : d_midx;    // the measured list (device memory), for the re-evaluations of W below
     int rc = build_innovation(M, plane, true, &m, &m_pad, &tab, strip_rows);
     cur_z = nullptr;
     cur_midx = nullptr;
@@ -1387,6 +1400,9 @@ struct Filter : FilterBase {
     rc = ensure_tilemap(npad_live / tile, ntr, ntc);
     if (rc) return rc;
 
+    // EKF_OPT_W_RECOMPUTE (fp32 MFMA path, several chunks): the W columns of chunk g + 1 come from the downdated Sigma
+    // instead of the right-looking GEMM update (see the option's comment in ekf_monoslam.h)
+    const bool recompute = kIsF32 && opt_mfma && opt_wrecompute && nchunks > 1 && tile == 128 && !opt_split_bf16 && !oneblock;
     int step = 0;
     bool b_inflight = false;
     for (int gi = 0; gi < nchunks; ++gi) {
@@ -1399,8 +1415,15 @@ struct Filter : FilterBase {
       // the last chunk has nothing left to overlap with: it runs on the main stream, on every CU
       const bool overlap = (stream_b != nullptr) && (gi + 1 < nchunks);
       hipStream_t ss = overlap ? stream_b : stream;
-      if (!overlap && b_inflight)                    // the solve reads W: only the last W update has to be done
-        HIPCHK(hipStreamWaitEvent(stream, ev_wu, 0));
+      if (!overlap && b_inflight) {
+        if (recompute) {                             // W of this chunk is re-evaluated from Sigma: every earlier downdate first
+          HIPCHK(hipEventRecord(ev_b, stream_b));
+          HIPCHK(hipStreamWaitEvent(stream, ev_b, 0));
+          b_inflight = false;
+        } else {                                     // the solve reads W: only the last W update has to be done
+          HIPCHK(hipStreamWaitEvent(stream, ev_wu, 0));
+        }
+      }
       if (overlap) {
         b_inflight = true;
         HIPCHK(hipEventRecord(ev_chain[gi], sc_));
@@ -1442,9 +1465,15 @@ struct Filter : FilterBase {
       // the chunk before the last: the last solve starts on that chunk's W update, not on its downdate.
       bool fuse = false;
       if constexpr (kIsF32)
-        fuse = opt_fuse_wu && (opt_fuse_wu > 1 || gi + 2 < nchunks) && opt_mfma && overlap && c1 < m_pad &&
+        fuse = opt_fuse_wu && (opt_fuse_wu > 1 || recompute || gi + 2 < nchunks) && opt_mfma && overlap && c1 < m_pad &&
                !opt_split_bf16 && tile == 128 && tri_count >= num_cus && counter_next + 8 <= kQueueCounters;
-      if (c1 < m_pad && !fuse) {
+      if (c1 < m_pad && !fuse && recompute) {
+        // only the innovation row (row npad_live of [W; nu^T]) is updated right-looking: nu^T[c1:] -= y_g^T L[c1:, g]^T
+        Scope sc(this, KID_WUPDATE, ss);
+        gemm<ROLE_WUPDATE, false, 64, 128>(d_V + (size_t)npad_live * ldy + c0, ldy, Y + (size_t)c1 * ldy + c0, ldy,
+                                           d_W + (size_t)npad_live * ldy + c1, ldy, nb, m_pad - c1, width, T(-1), T(1), 0, 0, 0,
+                                           0, 0, ss);
+      } else if (c1 < m_pad && !fuse) {
         Scope sc(this, KID_WUPDATE, ss);
         const int slots = 2 * (overlap ? num_cus - reserved_cus : num_cus);
         if (kIsF32 && opt_mfma && ((m_pad - c1) / 128) * ntr < slots)
@@ -1454,7 +1483,7 @@ struct Filter : FilterBase {
           gemm<ROLE_WUPDATE, false>(d_V + c0, ldy, Y + (size_t)c1 * ldy + c0, ldy, d_W + c1, ldy, npad_live + nb, m_pad - c1,
                                     width, T(-1), T(1), 0, 0, 0, 0, 0, ss);
       }
-      if (overlap && c1 < m_pad && !fuse) HIPCHK(hipEventRecord(ev_wu, stream_b));
+      if (overlap && c1 < m_pad && !fuse && !recompute) HIPCHK(hipEventRecord(ev_wu, stream_b));
       if (!overlap && b_inflight) {                  // earlier downdates must be done before Sigma is touched again
         HIPCHK(hipEventRecord(ev_b, stream_b));
         HIPCHK(hipStreamWaitEvent(stream, ev_b, 0));
@@ -1492,18 +1521,20 @@ struct Filter : FilterBase {
       if (fuse) {
         if constexpr (kIsF32) {
           Scope sc(this, KID_DOWNDATE, ss);               // W[:, c1:] -= V_g L[c1:, g]^T, then Sigma -= V_g V_g^T
+          // (recompute: of [W; nu^T] only the row tile that holds nu^T -- the rows of W are re-evaluated from Sigma)
+          const int nr2 = recompute ? 1 : (npad_live + nb) / 128, n2 = nr2 * ((m_pad - c1) / 128);
+          const int row2 = recompute ? npad_live / 128 : 0;
           if (sc.on) {
             const double w = std::min(c1, m) - std::min(c0, m);
-            prof_work[KID_DOWNDATE] += double(n) * n * w + 2.0 * (n + 1) * std::max(0, m - c1) * w;
+            prof_work[KID_DOWNDATE] += double(n) * n * w + 2.0 * (recompute ? 1 : n + 1) * std::max(0, m - c1) * w;
           }
-          const int nr2 = (npad_live + nb) / 128, n2 = nr2 * ((m_pad - c1) / 128);
           GemmArgs g{d_V + c0, ldy, d_V + c0, ldy, S(), ld, width, -1.0, 1.0, 2, 0, 0, 0, 0,
                      d_tilemap, n2 + tri_count, d_counters + counter_next, 0, 0, 1,
-                     Y + (size_t)c1 * ldy + c0, ldy, d_W + c1, ldy, n2, nr2};
+                     Y + (size_t)c1 * ldy + c0, ldy, d_W + c1, ldy, n2, nr2, row2};
           counter_next += 8;
           const int wgs = 2 * (num_cus - reserved_cus);
           k_gemm_mfma<ROLE_DOWNDATE, false><<<std::min(g.ntiles, wgs), 256, 0, ss>>>(g);
-          HIPCHK(hipEventRecord(ev_wu, stream_b));
+          if (!recompute) HIPCHK(hipEventRecord(ev_wu, stream_b));
         }
       } else if (!split_done && !allinone) {
         Scope sc(this, KID_DOWNDATE, ss);                 // Sigma -= V_g V_g^T (lower tiles + mirror)
@@ -1517,6 +1548,21 @@ struct Filter : FilterBase {
         else
           gemm<ROLE_DOWNDATE, false>(d_V + c0, ldy, d_V + c0, ldy, S(), ld, npad_live, npad_live, width, T(-1), T(1), 2, 0,
                                      0, 0, 0, ss, d_tilemap, tri_count);
+      }
+      if constexpr (kIsF32) {
+        if (recompute && gi + 1 < nchunks) {
+          // W[:, c1:c2) = Sigma' H^T for the features of the NEXT chunk, Sigma' = Sigma - sum_{g <= gi} V_g V_g^T (stream
+          // order: right behind this chunk's downdate, in front of the wait for the chain): the sequential form of the
+          // update.  Only these columns of Sigma' are read (a feature's six columns + the camera's), i.e. one more pass
+          // over Sigma in all; the right-looking GEMM update W[:, c1:] -= V_g L[c1:, g]^T of every chunk
+          // (2 n w_g (m - c1) flop) is not needed
+          Scope sc(this, KID_SIGMA_HT, ss);
+          const int s0 = c1 / 2, s1 = cend[gi + 1] * nb / 2;
+          constexpr int RB = 8;
+          dim3 grid((s1 - s0 + 127) / 128, (n + RB - 1) / RB);
+          k_sigma_ht_fast<RB><<<grid, 256, 0, ss>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, ip_list, M, plane, d_W, ldy, m_pad, N,
+                                                    s0, s1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        }
       }
     }
     if (b_inflight) {

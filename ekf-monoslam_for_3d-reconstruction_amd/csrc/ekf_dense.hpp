@@ -66,9 +66,11 @@ __global__ void k_sigma_ht(const T* __restrict__ S, int ld, int n,
                            const T* __restrict__ z = nullptr, const T* __restrict__ h = nullptr,
                            const T* __restrict__ mu = nullptr, T* __restrict__ nu = nullptr,
                            int* __restrict__ counters = nullptr, int* __restrict__ status = nullptr,
-                           T* __restrict__ q_old = nullptr) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;    // measurement slot
-  const int nslots = m_pad / 2;
+                           T* __restrict__ q_old = nullptr, int slot0 = 0, int slot_end = 0) {
+  // slots [slot0, slot_end) only (slot_end = 0: all of them): the columns of ONE column chunk of the factorisation,
+  // re-evaluated from the downdated Sigma (Filter::update, EKF_W_RECOMPUTE)
+  const int k = slot0 + blockIdx.x * blockDim.x + threadIdx.x;    // measurement slot
+  const int nslots = slot_end > 0 ? slot_end : m_pad / 2;
   if (nu != nullptr && blockIdx.y == gridDim.y - 1) {
     if (q_old && k < 4) q_old[k] = mu[3 + k];             // the quaternion before this update (k_update_oneblock_small)
     // one more slab of workgroups than the rows need: the innovation nu = z - h (k_innovation folded into this
@@ -129,6 +131,156 @@ __global__ void k_sigma_ht(const T* __restrict__ S, int ld, int n,
         }
         w[c] = v;
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// W = Sigma H^T for measured lists whose features sit next to each other in the state (the usual case: every visible
+// feature measured, all of them inverse-depth), fp32.  One workgroup = 128 slots x RB rows: the RB row segments of
+// Sigma the 128 features need (768 contiguous floats each, + 2 in front so that the 16-byte loads are aligned) and the 7
+// camera entries of each row are staged in LDS with every load in flight before the first LDS write; lane (slot, half)
+// then walks RB / 2 rows: 3 ds_read_b64 + the broadcast camera entries per row, the same sums in the same order as
+// k_sigma_ht (bit-identical), one float2 store per lane and row (1 KB contiguous per row).  A workgroup whose 128 slots
+// are not such a run (a measured subset, XYZ features, the padding / plane slots at the end of the list) takes
+// k_sigma_ht's path for its slots.  Used for the whole W in front of the factorisation and for the re-evaluation of
+// one column chunk from the downdated Sigma (slots [slot0, slot_end), EKF_OPT_W_RECOMPUTE).
+// ---------------------------------------------------------------------------------------
+template <int RB>
+__global__ void __launch_bounds__(256, RB <= 8 ? 6 : 3)
+k_sigma_ht_fast(const float* __restrict__ S, int ld, int n,
+                const float* __restrict__ Hc, const float* __restrict__ Hf,
+                const int* __restrict__ pos, const int* __restrict__ coding,
+                const int* __restrict__ midx, int M, int plane,
+                float* __restrict__ W, int ldy, int m_pad, int nfeat, int slot0, int slot_end,
+                const float* __restrict__ z, const float* __restrict__ h, const float* __restrict__ mu,
+                float* __restrict__ nu, int* __restrict__ counters, int* __restrict__ status, float* __restrict__ q_old) {
+  constexpr int SL = 128, SEG = 6 * SL + 4;              // floats of a row segment: 2 in front, 768, 2 behind
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  __shared__ __attribute__((aligned(16))) float seg[RB * SEG];
+  __shared__ __attribute__((aligned(16))) float cam[RB * 8];
+  const int tid = threadIdx.x;
+  if (nu != nullptr && blockIdx.y == gridDim.y - 1) {
+    // one more slab of workgroups than the rows need: nu = z - h, the work-queue heads, the quaternion before the update
+    // (exactly k_sigma_ht's slab)
+    const int k = blockIdx.x * blockDim.x + tid;
+    const int nslots = m_pad / 2;
+    if (q_old && k < 4) q_old[k] = mu[3 + k];
+    if (counters)
+      for (int c = k; c < kQueueCounters; c += gridDim.x * blockDim.x) counters[c] = 0;
+    if (k >= nslots) return;
+    if (k < M) check_measured_entry(midx, k, nfeat, status);
+#pragma unroll
+    for (int t = 2 * k; t < 2 * k + 2; ++t) {
+      float v = 0.f;
+      if (t < 2 * M) {
+        v = z[t] - h[2 * clamp_feature(midx[t >> 1], nfeat) + (t & 1)];
+      } else if (plane && t < 2 * M + 3) {
+        const int e = t - 2 * M;
+        v = -mu[e == 0 ? 1 : (e == 1 ? 4 : 6)];
+      }
+      nu[t] = v;
+    }
+    return;
+  }
+  const int s = tid & (SL - 1), half = tid >> 7;
+  const int kbase = slot0 + blockIdx.x * SL;
+  const int k = kbase + s;
+  const int nslots = slot_end > 0 ? slot_end : m_pad / 2;
+  const int row0 = blockIdx.y * RB, row1 = min(row0 + RB, n);
+  // is this workgroup's stretch of the list a run of inverse-depth features that are neighbours in the state?
+  int fi = -1, p = 0, fs = 6;
+  if (k < M && k < nslots) {
+    fi = clamp_feature(midx[k], nfeat);
+    p = pos[fi];
+    fs = coding[fi] ? 3 : 6;
+  }
+  int p_first = 0;
+  if (kbase < M) p_first = pos[clamp_feature(midx[kbase], nfeat)];
+  // the compact Jacobian of the lane's feature: requested together with pos / coding (one level of the dependent chain
+  // midx -> {pos, coding, Hc, Hf} -> row segments, not two)
+  float hc[14], hf[12];
+  {
+    const int fj = max(fi, 0);
+#pragma unroll
+    for (int t = 0; t < 14; ++t) hc[t] = Hc[(size_t)fj * 14 + t];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) hf[t] = Hf[(size_t)fj * 12 + t];
+  }
+  const bool lane_ok = fi >= 0 && fs == 6 && p == p_first + 6 * s && ((p_first - 2) & 3) == 0;
+  const bool fast = __syncthreads_and(lane_ok ? 1 : 0) != 0;
+  if (!fast) {
+    // k_sigma_ht's path for (slot k, this half of the rows)
+    if (k >= nslots) return;
+    const int ra = row0 + half * (RB / 2), rb = min(ra + RB / 2, row1);
+    if (k < M) {
+      for (int i = ra; i < rb; ++i) {
+        const float* srow = S + (size_t)i * ld;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 7; ++t) { const float v = srow[t]; a0 += v * hc[t]; a1 += v * hc[7 + t]; }
+        if (fs == 6) {
+#pragma unroll
+          for (int t = 0; t < 6; ++t) { const float v = srow[p + t]; a0 += v * hf[t]; a1 += v * hf[6 + t]; }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 3; ++t) { const float v = srow[p + t]; a0 += v * hf[t]; a1 += v * hf[6 + t]; }
+        }
+        float* w = W + (size_t)i * ldy + 2 * k;
+        w[0] = a0; w[1] = a1;
+      }
+    } else {
+      for (int i = ra; i < rb; ++i) {
+        float* w = W + (size_t)i * ldy;
+        for (int c = 2 * k; c < 2 * k + 2; ++c) {
+          float v = 0.f;
+          if (plane && c >= 2 * M && c < 2 * M + 3) {
+            const int e = c - 2 * M;
+            v = S[(size_t)i * ld + (e == 0 ? 1 : (e == 1 ? 4 : 6))];
+          }
+          w[c] = v;
+        }
+      }
+    }
+    return;
+  }
+  // stage: RB x (SEG / 4 = 193) float4 of the feature segments + RB x 2 float4 of the camera columns
+  constexpr int Q = SEG / 4, TOT = RB * Q, PER = (TOT + 255) / 256;
+  const float* sbase = S + (p_first - 2);
+  // every load unconditional (indices clamped to the last slot / the last live row: a guarded load makes the compiler
+  // branch around and wait for each one), all of them in flight before the first LDS write
+  f4 v[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int idx = min(tid + 256 * u, TOT - 1);
+    const int r = idx / Q, q = idx - r * Q;
+    v[u] = *reinterpret_cast<const f4*>(sbase + (size_t)min(row0 + r, n - 1) * ld + 4 * q);
+  }
+  const f4 cv = *reinterpret_cast<const f4*>(S + (size_t)min(row0 + ((tid >> 1) & (RB - 1)), n - 1) * ld + 4 * (tid & 1));
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int idx = tid + 256 * u;
+    if (idx < TOT) *reinterpret_cast<f4*>(seg + 4 * idx) = v[u];      // seg[r][4 q ..]: idx = r Q + q, SEG = 4 Q
+  }
+  if (tid < 2 * RB) *reinterpret_cast<f4*>(cam + 4 * tid) = cv;
+  __syncthreads();
+  const int ra = half * (RB / 2);
+#pragma unroll
+  for (int r = ra; r < ra + RB / 2; ++r) {
+    const int i = row0 + r;
+    if (i < n) {
+      const float* sr = seg + r * SEG + 2 + 6 * s;
+      const f2 x0 = *reinterpret_cast<const f2*>(sr), x1 = *reinterpret_cast<const f2*>(sr + 2), x2 = *reinterpret_cast<const f2*>(sr + 4);
+      const f4 c0 = *reinterpret_cast<const f4*>(cam + 8 * r), c1 = *reinterpret_cast<const f4*>(cam + 8 * r + 4);
+      const float cvv[7] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2]};
+      const float fv[6] = {x0[0], x0[1], x1[0], x1[1], x2[0], x2[1]};
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int t = 0; t < 7; ++t) { a0 += cvv[t] * hc[t]; a1 += cvv[t] * hc[7 + t]; }
+#pragma unroll
+      for (int t = 0; t < 6; ++t) { a0 += fv[t] * hf[t]; a1 += fv[t] * hf[6 + t]; }
+      *reinterpret_cast<f2*>(W + (size_t)i * ldy + 2 * k) = f2{a0, a1};
     }
   }
 }
@@ -249,6 +401,7 @@ struct GemmArgs {
   const void* B2; int ldb2;
   void* C2; int ldc2;
   int n2, nr2;
+  int row2;                                     // first row tile of the second product (its tiles are rows row2 .. row2 + nr2 - 1)
 };
 constexpr int kSecondProduct = 0x10000;         // flag on bj for a tile of the second product
 constexpr int kHalfTile = 0x20000;              // flag on bi: 64-row half tile, bi & 0xffff in 64-row units (k_gemm_mfma, downdate)
@@ -270,7 +423,7 @@ __device__ __forceinline__ bool gemm_next_tile(const GemmArgs& g, int* s_tile, i
   const int t = __builtin_amdgcn_readfirstlane(*s_tile);   // workgroup-uniform: the tile's address arithmetic stays scalar
   if (t >= g.ntiles) return false;
   if (t < g.n2) {
-    bi = t % g.nr2;
+    bi = g.row2 + t % g.nr2;
     bj = (t / g.nr2) | kSecondProduct;
   } else {
     bi = g.tile_map[2 * (t - g.n2)];

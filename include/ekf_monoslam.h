@@ -101,7 +101,15 @@ enum ekf_option {
    * when the innovation fits one 128-column block (2 M + 3 <= 128: the reference's operating point of <= 35 features),
    * gain solve + state update as one launch without the panel step (same sums in another order: fp32 rounding).
    * 0: one launch per kernel (what the per-kernel profile of EKF_OPT_PROFILE = 2 times). */
-  EKF_OPT_FUSED_LAUNCHES = 6
+  EKF_OPT_FUSED_LAUNCHES = 6,
+  /* Chunked factorisation, fp32 MFMA path (round 4).  1 (default): after the downdate of column chunk g the columns of
+   * W = Sigma H^T of the NEXT chunk are re-evaluated from the downdated Sigma -- the sequential form of the update:
+   * W'_h = (Sigma - sum_{g<h} V_g V_g^T) H_h^T, algebraically what the right-looking GEMM update
+   * W_h -= V_g L_hg^T produces, for 26 n w_h flop and one read of those columns of Sigma instead of 2 n w_g w_h flop
+   * (15 of the 99 GFLOP of a step at N = M = 1000; 15 % at N = 4000); only the innovation row is still updated
+   * right-looking (inside the downdate launch).  0: the right-looking W update of rounds 1-3 (the sharded step keeps
+   * it: there the W update of a rank runs beside the gather of V_g).  Same result up to fp32 rounding. */
+  EKF_OPT_W_RECOMPUTE = 7
 };
 
 /* Fills `cfg` with the reference defaults (ConfigVSLAM.cpp:27-47, camModel.hpp:22-31). */
