@@ -218,6 +218,7 @@ struct Filter : FilterBase {
     return kIsF32 && opt_mfma && opt_solve_s2 && (opt_solve_s2 > 1 || (width / 128) * (npad_live / 64) <= 2 * num_cus);   // (2: always, for A/B runs)
   }
   int opt_fused = 1;                                    // EKF_OPT_FUSED_LAUNCHES: k_predict_fused, k_solve_state_oneblock, k_update_oneblock_small
+  int opt_lazy_trailing = 0;                            // EKF_LAZY_TRAILING=1 (opt-in, A/B): the chain's trailing update stays inside the chunk, one deferred update per chunk
   int opt_wrecompute = 1;                               // EKF_OPT_W_RECOMPUTE / EKF_W_RECOMPUTE: next chunk's W re-evaluated from the downdated Sigma
   int opt_fuse_wu = 1;                                  // EKF_FUSE_WU: 0 never, 1 every overlapped chunk but the one before the last, 2 every overlapped chunk
   int env_chunks[8] = {}, env_nchunks = 0;               // EKF_CHUNKS="5,10,14,16": tuning knob (block steps)
@@ -410,6 +411,7 @@ struct Filter : FilterBase {
         HIPCHK(hipStreamCreateWithFlags(&stream_c, hipStreamNonBlocking));
       }
       if (const char* e = getenv("EKF_FUSE_WU")) opt_fuse_wu = atoi(e);
+      if (const char* e = getenv("EKF_LAZY_TRAILING")) opt_lazy_trailing = atoi(e) ? 1 : 0;
       if (const char* e = getenv("EKF_W_RECOMPUTE")) opt_wrecompute = atoi(e) ? 1 : 0;   // = EKF_OPT_W_RECOMPUTE, for A/B runs
       if (const char* e = getenv("EKF_SOLVE_S2")) opt_solve_s2 = atoi(e);
       if (const char* e = getenv("EKF_FUSED_LAUNCHES")) opt_fused = atoi(e) ? 1 : 0;   // = EKF_OPT_FUSED_LAUNCHES, for A/B runs
@@ -1309,14 +1311,32 @@ struct Filter : FilterBase {
         T* P = Y + (size_t)r0 * ldy + j;
         launch_panel(P, Dj, vrows, sc_);
       }
-      if (r0 < m_pad) {
+      // EKF_LAZY_TRAILING=1 (round 4, NOT the default): inside a chunk the trailing update only covers the columns of THAT
+      // chunk (what its own steps read); the columns of the later chunks get ONE rank-(chunk width) update when the chain
+      // leaves the chunk (chain_deferred): a third of the tiles per step, 1.153 -> 1.144 ms at N = M = 1000 -- and Sigma
+      // twice as far from the fp64 oracle (frame 1: 5.1e-5 against 2.2e-5, tools/acc_knobs.py): S cancels by orders of
+      // magnitude under the first block columns, and products added to an accumulator that still holds the whole sum are
+      // rounded at ITS magnitude; the step-by-step update rounds each rank-128 term against the already reduced S
+      const int tcols = (opt_lazy_trailing && c1 < m_pad) ? c1 - r0 : m_pad - r0;
+      if (r0 < m_pad && tcols > 0) {
         Scope sc(this, KID_CHOL_TRAILING, sc_);              // Y[r0.., r0:] -= P P_S^T; strip rows stop at c1
         const T* P = Y + (size_t)r0 * ldy + j;
         T* C = Y + (size_t)r0 * ldy + r0;
-        gemm<ROLE_TRAILING, false, 64, 64>(P, ldy, P, ldy, C, ldy, vrows, m_pad - r0, nb, T(-1), T(1), 1, r0, r0, 0, 0,
+        gemm<ROLE_TRAILING, false, 64, 64>(P, ldy, P, ldy, C, ldy, vrows, tcols, nb, T(-1), T(1), 1, r0, r0, 0, 0,
                                            sc_, nullptr, 0, m_pad, c1);
       }
     }
+  }
+  // ... and the update of the later chunks' columns the steps of chunk [c0, c1) left out (EKF_LAZY_TRAILING): launched
+  // AFTER the event that tells the second stream the chunk is factored -- its solve does not read those columns
+  void chain_deferred(int c0, int c1, int m_pad, hipStream_t sc_) {
+    if (!opt_lazy_trailing || c1 >= m_pad || c1 <= c0) return;
+    T* Y = d_Y;
+    Scope sc(this, KID_CHOL_TRAILING, sc_);                  // Y[c1.., c1..] -= P_g P_g^T, P_g = L[c1.., c0:c1): lower tiles
+    const T* P = Y + (size_t)c1 * ldy + c0;
+    T* C = Y + (size_t)c1 * ldy + c1;
+    gemm<ROLE_TRAILING, false, 64, 64>(P, ldy, P, ldy, C, ldy, m_pad - c1, m_pad - c1, c1 - c0, T(-1), T(1), 1, c1, c1, 0, 0,
+                                       sc_);
   }
 
   // ---- a8-a11 update ---------------------------------------------------------------------
@@ -1429,6 +1449,7 @@ struct Filter : FilterBase {
         HIPCHK(hipEventRecord(ev_chain[gi], sc_));
         HIPCHK(hipStreamWaitEvent(stream_b, ev_chain[gi], 0));
       }
+      chain_deferred(c0, c1, m_pad, sc_);
       if (oneblock) {
         if constexpr (kIsF32) {
           const int nrb = npad_live / 64, nt64 = nrb * (nrb + 1) / 2;
@@ -2679,6 +2700,7 @@ struct Filter : FilterBase {
         HIPCHK(hipEventRecord(ev_b, stream_b));
         HIPCHK(hipStreamWaitEvent(stream, ev_b, 0));
       }
+      chain_deferred(c0, c1, m_pad, stream);
       for (const Rows& rr : ranges) {
         if (rr.count == 0) continue;
         const size_t off = (size_t)rr.r0 * ldy;

@@ -321,19 +321,41 @@ __global__ void k_innovation_cov(const T* __restrict__ W, int ldy,
   // blockIdx.y < nfb: KB measured features each; the blocks after them: 8 rows each of the plane / padding rows
   const int nfb = max(1, (k_end - k_begin + KB - 1) / KB);
   const int k0 = k_begin + blockIdx.y * KB;               // measured features [k_begin, k_end)
-  if (blockIdx.y < nfb)
-  for (int k = k0; k < min(k0 + KB, k_end); ++k) {
-    const int fi = clamp_feature(midx[k], nfeat);
-    const int p = pos[fi];
-    const int fs = coding[fi] ? 3 : 6;
+  if (blockIdx.y < nfb) {
+  // the KB features of the block: their (uniform) list entries first, then EVERY row of W they need requested before
+  // the first sum (round 4: one feature at a time the loop was a chain of KB dependent scalar -> vector load rounds,
+  // 27 us for 75 MB; the rows of a 3-entry feature are requested at its last valid row and dropped by a select, so
+  // that no load sits behind a branch)
+  int pk[KB], fsk[KB], fik[KB];
+#pragma unroll
+  for (int u = 0; u < KB; ++u) {
+    const int k = min(k0 + u, k_end - 1);
+    fik[u] = clamp_feature(midx[max(k, 0)], nfeat);
+    pk[u] = pos[fik[u]];
+    fsk[u] = coding[fik[u]] ? 3 : 6;
+  }
+  T wv[KB][6];
+#pragma unroll
+  for (int u = 0; u < KB; ++u)
+#pragma unroll
+    for (int t = 0; t < 6; ++t) wv[u][t] = W[(size_t)(pk[u] + min(t, fsk[u] - 1)) * ldy + c];
+#pragma unroll
+  for (int u = 0; u < KB; ++u) {
+    const int k = k0 + u;
+    if (k >= k_end) break;
+    const int fi = fik[u];
+    const int fs = fsk[u];
     const T* hc = Hc + (size_t)fi * 14;
     const T* hf = Hf + (size_t)fi * 12;
     T a0 = T(0), a1 = T(0);
 #pragma unroll
     for (int t = 0; t < 7; ++t) { a0 += hc[t] * wc[t]; a1 += hc[7 + t] * wc[t]; }
-    for (int t = 0; t < fs; ++t) {
-      const T v = W[(size_t)(p + t) * ldy + c];
-      a0 += hf[t] * v; a1 += hf[6 + t] * v;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      if (t < fs) {                       // (uniform: fs is a per-feature scalar)
+        const T v = wv[u][t];
+        a0 += hf[t] * v; a1 += hf[6 + t] * v;
+      }
     }
     if (c == 2 * k) a0 += r_pix;
     if (c == 2 * k + 1) a1 += r_pix;
@@ -344,6 +366,7 @@ __global__ void k_innovation_cov(const T* __restrict__ W, int ldy,
       Zid[(size_t)(2 * k) * ldy + c] = strip_is_one(tab, 2 * k, c) ? T(1) : T(0);
       Zid[(size_t)(2 * k + 1) * ldy + c] = strip_is_one(tab, 2 * k + 1, c) ? T(1) : T(0);
     }
+  }
   }
   if (blockIdx.y >= nfb) {
     const int rb = 2 * M + (blockIdx.y - nfb) * 8;

@@ -980,7 +980,7 @@ def test_n4000_matches_fp64_oracle_sketch():
     for k, r in enumerate(rows[4:]):                        # feature rows one by one (a camera row would hide them)
         assert bound(f"Sigma row {k + 4} of the sketch vs fp64 oracle", relf(S[r], g["rows"][k + 4]), 25 * t["S"])   # one row: first run 1.3e-4
     proj = npar.blocked_matmul(S, npar.sketch_matrix(S.shape[0]))
-    assert bound("Sigma R (4 Gaussian vectors) vs fp64 oracle", relf(proj, g["proj"]), 5 * t["S"])
+    assert bound("Sigma R (4 Gaussian vectors) vs fp64 oracle", relf(proj, g["proj"]), 10 * t["S"])
     # the sketch's estimate of |Sigma_hip - Sigma_oracle|_F / |Sigma_oracle|_F
     est = float(np.linalg.norm(proj - g["proj"]) / np.sqrt(proj.shape[1]) / float(g["fro"]))
     assert bound("estimated rel. Frobenius error of Sigma vs fp64 oracle", est, 5 * t["S"])
