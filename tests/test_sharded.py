@@ -524,7 +524,9 @@ def test_hip_shard_update_flow_three_ranks_vs_oracle(dtype):
         assert r["two_stage_0"] and r["two_stage_1"] and r["n_find"] and r["image_refused"], (rank, r)
         assert bound("rank S2x2 vs oracle", r["S2"], 2e-5 if f32 else 1e-10)
         assert bound("rank St vs oracle", r["St"], 2e-5 if f32 else 1e-10)
-        assert bound("rank mu vs oracle", r["mu"], 5e-5 if f32 else 1e-11)
+        # (fp32: measured 4.8e-5 -- the distance of the fp32 ORACLE from the truth, not of the HIP path: against the fp64
+        # oracle below the same state is at 1.1e-5, and the yardstick line holds this one to 1.5 x |o32 - o64| + 2e-5)
+        assert bound("rank mu vs oracle", r["mu"], 1e-4 if f32 else 1e-11)
         assert bound("rank Sigma rows vs oracle", r["Sigma"], 2e-3 if f32 else 1e-9)
         if f32:
             # Against the fp64 oracle run beside the fp32 one (same measurements, same inlier / rescue decisions): the

@@ -10,7 +10,7 @@ import torch
 from ekf_monoslam_amd import synthetic
 cfg = pkg.kinect_config()
 N = int(os.environ.get("KNOB_N", "1000"))
-frames = 170
+frames = int(os.environ.get("KNOB_FRAMES", "170"))      # 10 warm-up + (frames - 20) timed steps
 px0, z = synthetic.measurement_stream(cfg, N, frames, sigma_px=0.5)
 d_z = torch.from_numpy(z.reshape(frames, -1)).cuda().contiguous()
 d_idx = torch.arange(N, dtype=torch.int32, device="cuda")
@@ -35,10 +35,10 @@ for rep in range(2):
             f.predict(); f.update_device(d_z.data_ptr() + k * 8 * N, d_idx.data_ptr(), N)
         f.synchronize(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for k in range(10, 160):
+        for k in range(10, frames - 10):
             f.predict(); f.update_device(d_z.data_ptr() + k * 8 * N, d_idx.data_ptr(), N)
         f.synchronize()
-        dt = (time.perf_counter() - t0) / 150
+        dt = (time.perf_counter() - t0) / (frames - 20)
         mu = f.getFullState()
         if base is None:
             base = mu
