@@ -400,15 +400,29 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
                              "--pipeline 0 runs one launch" % pieces)
                             if pieces > 1 or args.pipeline != 0 else "one launch per step"}
 
-    # the whole step against the f32 MFMA peak: algorithmic flop of this formulation (SURVEY 8d / DESIGN 4: symmetric-half
-    # downdate n^2 m, triangular solve n m^2, Cholesky m^3 / 3; the O(13 n m) of W and S and the strips are < 1 %)
-    step_flop = float(n) * n * m + float(n) * m * m + float(m) ** 3 / 3.0
+    # the whole step against the f32 MFMA peak: algorithmic flop of the formulation THIS run executed, from the library's
+    # own column chunks (ekf_get_chunk_plan): symmetric-half downdate n^2 m; V_g = W_g Z_gg per chunk, n w_g^2 (Z_gg upper
+    # triangular); right-looking W update 2 n w_g (m - c1_g) per chunk, or -- EKF_OPT_W_RECOMPUTE, the default -- the
+    # re-evaluation of the later chunks' W from the downdated Sigma, 26 n w; Cholesky of S m^3 / 3 and the chunk
+    # inverses sum w_g^3 / 3; W and S in front, 26 n m + 26 m^2.  (Rounds 1-3 ran 99 GFLOP per step at N = 1000; the
+    # sequential form runs 86.)
+    block, ends, wrec = last.chunkPlan()
+    widths = [(e - (ends[g - 1] if g else 0)) * block for g, e in enumerate(ends)] or [m]
+    c1s = [e * block for e in ends] or [m]
+    solve_flop = sum(float(n) * w * w for w in widths)
+    wupd_flop = 0.0 if wrec else sum(2.0 * n * w * max(0, m - c1) for w, c1 in zip(widths, c1s))
+    reval_flop = sum(26.0 * n * w for w in widths[1:]) if wrec else 0.0
+    chol_flop = float(m) ** 3 / 3.0 + sum(float(w) ** 3 / 3.0 for w in widths)
+    step_flop = float(n) * n * m + solve_flop + wupd_flop + reval_flop + chol_flop + 26.0 * n * m + 26.0 * m * m
     ach_step = step_flop / (ms_per_step * 1e-3) / 1e12
     roofline_step = {"bound": "mfma" if n_feat >= 600 else "latency", "achieved": round(ach_step, 2), "peak": PEAK_F32_MFMA_TF,
                      "unit": "TFLOP/s", "frac": round(ach_step / PEAK_F32_MFMA_TF, 4), "traffic": None,
                      "algorithmic_flop_per_step": step_flop,
-                     "basis": "whole step: n^2 m (downdate, symmetric half) + n m^2 (V = W L^-T) + m^3 / 3 (Cholesky of S) "
-                              "flop / ms_per_step, against the f32 MFMA peak"}
+                     "flop_breakdown": {"downdate": float(n) * n * m, "solve": solve_flop, "w_update": wupd_flop,
+                                        "w_reevaluation": reval_flop, "cholesky_and_chunk_inverses": chol_flop},
+                     "chunk_ends_block_steps": ends, "block": block, "w_recompute": wrec,
+                     "basis": "whole step: algorithmic flop of the formulation executed (the library's column chunks) / "
+                              "ms_per_step, against the f32 MFMA peak"}
 
     # HBM traffic per launch: measured by two rocprofv3 --pmc child passes of this run (live_pmc_traffic); when those are
     # not available (child of a profiler, no rocprofv3, --no-live-traffic) from the committed PMC passes, which belong to

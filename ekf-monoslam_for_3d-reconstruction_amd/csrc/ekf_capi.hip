@@ -89,6 +89,7 @@ struct FilterBase {
   virtual int profile_read(int, double*, long long*) = 0;
   virtual int profile_reset() = 0;
   virtual int profile_work(int, double*) = 0;
+  virtual int chunk_plan(int*, int, int*, int*) = 0;
   virtual void* dev_mu() = 0;
   virtual void* dev_sigma(int*) = 0;
   virtual int export_points(void*, int) = 0;
@@ -678,7 +679,6 @@ struct Filter : FilterBase {
   }
   int set_frame(const unsigned char* gray, int width, int height, int stride) override {
     HIPCHK(hipSetDevice(device));
-    if (sh_on) FAIL(EKF_ERR_UNSUPPORTED, "the image side (frames, templates, NCC search) is not available on a sharded filter");
     if (!gray || width <= 0 || height <= 0 || stride < width) FAIL(EKF_ERR_ARG, "bad frame");
     if (width != cam.width || height != cam.height)
       FAIL(EKF_ERR_ARG, "frame size differs from ekf_config image_width / image_height");
@@ -700,7 +700,6 @@ struct Filter : FilterBase {
   }
   int set_patch(int index, const unsigned char* data) override {
     HIPCHK(hipSetDevice(device));
-    if (sh_on) FAIL(EKF_ERR_UNSUPPORTED, "the image side (frames, templates, NCC search) is not available on a sharded filter");
     if (index < 0 || index >= N || !data) FAIL(EKF_ERR_ARG, "feature index out of range");
     int rc = ensure_image_buffers();
     if (rc) return rc;
@@ -741,10 +740,12 @@ struct Filter : FilterBase {
   }
   int find_matches(double threshold, void* z, unsigned char* found, float* score) override {
     HIPCHK(hipSetDevice(device));
-    if (sh_on) FAIL(EKF_ERR_UNSUPPORTED, "the image side (frames, templates, NCC search) is not available on a sharded filter");
     if (!have_frame) FAIL(EKF_ERR_STATE, "ekf_find_matches needs ekf_set_frame");
     if (!have_meas) FAIL(EKF_ERR_STATE, "ekf_find_matches needs the predictions of ekf_predict / ekf_measure");
     if (N == 0) return EKF_OK;
+    // (sharded filter: the frame, the templates and -- after ekf_predict's "reassemble H" -- h are replicated, the 2x2 St
+    // blocks are owner-computed and all-gathered by ensure_sd(), a COLLECTIVE; every rank then searches every feature:
+    // the matching templates the search rewrites stay identical on every rank, and nothing else is exchanged)
     int rc = ensure_sd();
     if (rc) return rc;
     {
@@ -1592,6 +1593,7 @@ struct Filter : FilterBase {
       b_inflight = false;
     }
     last_nchunks = nchunks;
+    last_recompute = recompute;
     for (int g = 0; g < nchunks; ++g) last_cend[g] = cend[g];
     const T* V = d_V;
     const T* yv = d_V + (size_t)npad_live * ldy;
@@ -2577,7 +2579,7 @@ struct Filter : FilterBase {
     have_update = false;
     have_meas = true;
     have_sd = false;
-    return EKF_OK;
+    return launch_blur();                                  // predicted blur of every template (replicated, like the templates)
   }
 
   // The sharded EKF update block for the measured list `idx` (host, strictly ascending), z resident on the device.
@@ -2751,6 +2753,7 @@ struct Filter : FilterBase {
     }
     HIPCHK(hipGetLastError());
     last_nchunks = nchunks;
+    last_recompute = false;
     for (int g = 0; g < nchunks; ++g) last_cend[g] = cend[g];
     {
       Scope sc(this, KID_STATE_UPDATE);                    // mu is replicated: every rank adds V y over all rows
@@ -2811,6 +2814,14 @@ struct Filter : FilterBase {
     if (ms) *ms = prof_ms[kid];
     if (cnt) *cnt = prof_cnt[kid];
     return EKF_OK;
+  }
+  bool last_recompute = false;
+  int chunk_plan(int* ends, int max_chunks, int* block, int* wrec) override {
+    if (block) *block = NB();
+    if (wrec) *wrec = last_recompute ? 1 : 0;
+    if (last_cend[0] == 0) return 0;                          // no update yet
+    for (int g = 0; g < last_nchunks && g < max_chunks; ++g) if (ends) ends[g] = last_cend[g];
+    return last_nchunks;
   }
   int profile_work(int kid, double* flop) override {
     if (kid < 0 || kid >= KID_COUNT) FAIL(EKF_ERR_ARG, "kernel id out of range");
@@ -2969,6 +2980,10 @@ const char* ekf_profile_kernel_name(int kid) { return (kid >= 0 && kid < ekf::KI
 int ekf_profile_read(ekf_filter* f, int kid, double* ms, long long* cnt) { IMPL_OR_ARG(f); return f->impl->profile_read(kid, ms, cnt); }
 int ekf_profile_reset(ekf_filter* f) { IMPL_OR_ARG(f); return f->impl->profile_reset(); }
 int ekf_profile_work(ekf_filter* f, int kid, double* flop) { IMPL_OR_ARG(f); return f->impl->profile_work(kid, flop); }
+int ekf_get_chunk_plan(ekf_filter* f, int* ends, int max_chunks, int* block, int* w_recompute) {
+  if (!f || !f->impl) return 0;
+  return f->impl->chunk_plan(ends, max_chunks, block, w_recompute);
+}
 
 int ekf_rescue_high_innovation(ekf_filter* f, const void* cam, const void* z, const int* idx, int M, double thr,
                                unsigned char* out) {

@@ -397,6 +397,13 @@ class VSlamFilter:
                 out[self._lib.ekf_profile_kernel_name(k).decode()] = w.value
         return out
 
+    def chunkPlan(self):
+        """(block rows, [block step at which each column chunk of the last update ended], W re-evaluated?)."""
+        ends = (C.c_int * 8)()
+        block, wrec = C.c_int(0), C.c_int(0)
+        k = int(self._lib.ekf_get_chunk_plan(self._h, ends, 8, C.byref(block), C.byref(wrec)))
+        return block.value, [int(ends[g]) for g in range(min(k, 8))], bool(wrec.value)
+
     def profile_reset(self):
         self._check(self._lib.ekf_profile_reset(self._h))
 

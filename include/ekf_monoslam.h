@@ -34,7 +34,8 @@ extern "C" {
 
 /* 3 (round 3): + ekf_export_points_table, ekf_get_feature_ids, ekf_set_feature_meta, ekf_num_archived,
  * EKF_OPT_FUSED_LAUNCHES; the sharded filter accepts the whole update flow; - ekf_debug_flow_trace */
-#define EKF_ABI_VERSION 3
+/* 4 (round 4): + EKF_OPT_W_RECOMPUTE (default on), ekf_get_chunk_plan; the map getters are collective on a sharded filter */
+#define EKF_ABI_VERSION 4
 
 typedef struct ekf_filter ekf_filter;
 
@@ -326,6 +327,12 @@ int ekf_profile_reset(ekf_filter* f);
  * n^2 x the real columns of the chunk (symmetric half), plus 2 (n+1) (m - c1) x those columns where the launch also
  * carries the W update of its chunk). */
 int ekf_profile_work(ekf_filter* f, int kernel_id, double* flop);
+/* How the last ekf_update factored S (what the algorithmic flop of a step depends on): `block` = rows of a block step
+ * (128 fp32 MFMA, 64 otherwise), ends[g] = block step at which column chunk g ends (the last one = m_pad / block),
+ * `w_recompute` = 1 if the W columns of the later chunks were re-evaluated from the downdated Sigma (EKF_OPT_W_RECOMPUTE)
+ * rather than updated right-looking.  Returns the number of chunks (0 before the first update; at most `max_chunks`
+ * entries are written). */
+int ekf_get_chunk_plan(ekf_filter* f, int* ends, int max_chunks, int* block, int* w_recompute);
 
 /* ---- multi-GPU: row-panel sharding, one process per GPU ----------------------------------------
  * Every rank holds the same filter (same calls in the same order on every rank: add / remove / convert / predict /
@@ -369,8 +376,11 @@ typedef struct ekf_shard_info {
  * ekf_update_two_stage, ekf_ransac_1point (every rank evaluates the hypotheses on the listed features it owns, the
  * partial inlier counts are all-gathered), ekf_rescue_high_innovation and the 2x2 St blocks behind ekf_get_predictions /
  * ekf_get_search_ellipses (owner-computes, the blocks are all-gathered), ekf_innovation_covariance; under sharding their
- * measured lists must be strictly ascending.  The image side (ekf_set_frame, ekf_set_patch, ekf_find_matches) is
- * refused with EKF_ERR_UNSUPPORTED.  world = 1 needs no callback.
+ * measured lists must be strictly ascending.  Round 4: the image side (ekf_set_frame, ekf_set_patch, ekf_find_matches,
+ * the predicted blur inside ekf_predict) works on a sharded filter too -- frame and templates are replicated (every
+ * rank makes the same calls), the 2x2 blocks the search gates with are all-gathered, and every rank searches every
+ * feature (at most 124 us at N = 1000, far below one exchange): the templates stay identical on every rank.
+ * world = 1 needs no callback.
  *
  * COLLECTIVE CONTRACT.  On a sharded filter (world > 1) the following entry points run one or more all-gathers and are
  * therefore COLLECTIVE: every rank must call them, with the same arguments, in the same order relative to each other --
@@ -380,6 +390,7 @@ typedef struct ekf_shard_info {
  *   3 x 3 blocks), ekf_innovation_covariance, ekf_ransac_1point, ekf_rescue_high_innovation,
  *   ekf_get_predictions WITH s2 and ekf_get_search_ellipses (the 2x2 St blocks; gathered once per predict, so the
  *   first of these calls after a predict is the collective one -- make the same calls on every rank),
+ *   ekf_find_matches (the same 2x2 blocks),
  *   ekf_feature_xyz, ekf_export_points, ekf_export_points_table (round 4: a feature's covariance block is valid on
  *   its owner only; the owners' diagonal blocks are all-gathered first, so every rank returns the same table).
  * Local (no exchange): ekf_add_feature, ekf_get_state, ekf_get_sigma_block (valid for camera + own rows),
