@@ -219,6 +219,8 @@ struct Filter : FilterBase {
     return kIsF32 && opt_mfma && opt_solve_s2 && (opt_solve_s2 > 1 || (width / 128) * (npad_live / 64) <= 2 * num_cus);   // (2: always, for A/B runs)
   }
   int opt_fused = 1;                                    // EKF_OPT_FUSED_LAUNCHES: k_predict_fused, k_solve_state_oneblock, k_update_oneblock_small
+  int opt_solve_one_per_cu = 1;                         // EKF_SOLVE_ONE_PER_CU: the last solve on one workgroup per CU when it has 1 .. 2 tiles per CU
+  bool solve_one_per_cu_now = false;
   int opt_lazy_trailing = 0;                            // EKF_LAZY_TRAILING=1 (opt-in, A/B): the chain's trailing update stays inside the chunk, one deferred update per chunk
   int opt_wrecompute = 1;                               // EKF_OPT_W_RECOMPUTE / EKF_W_RECOMPUTE: next chunk's W re-evaluated from the downdated Sigma
   int opt_fuse_wu = 1;                                  // EKF_FUSE_WU: 0 never, 1 every overlapped chunk but the one before the last, 2 every overlapped chunk
@@ -412,6 +414,7 @@ struct Filter : FilterBase {
         HIPCHK(hipStreamCreateWithFlags(&stream_c, hipStreamNonBlocking));
       }
       if (const char* e = getenv("EKF_FUSE_WU")) opt_fuse_wu = atoi(e);
+      if (const char* e = getenv("EKF_SOLVE_ONE_PER_CU")) opt_solve_one_per_cu = atoi(e) ? 1 : 0;
       if (const char* e = getenv("EKF_LAZY_TRAILING")) opt_lazy_trailing = atoi(e) ? 1 : 0;
       if (const char* e = getenv("EKF_W_RECOMPUTE")) opt_wrecompute = atoi(e) ? 1 : 0;   // = EKF_OPT_W_RECOMPUTE, for A/B runs
       if (const char* e = getenv("EKF_SOLVE_S2")) opt_solve_s2 = atoi(e);
@@ -1079,7 +1082,8 @@ struct Filter : FilterBase {
       counter_next += 8;
       // persistent grid: two workgroups per CU the stream may use
       const bool side = (st == stream_b);
-      const int wgs = 2 * (side ? (num_cus - reserved_cus) : num_cus);
+      int wgs = 2 * (side ? (num_cus - reserved_cus) : num_cus);
+      if (ROLE == ROLE_SOLVE && solve_one_per_cu_now) wgs = num_cus;      // (see the last chunk's solve in update())
       grid = dim3(std::min(ntiles, wgs), 1);
     }
     if constexpr (kIsF32) {
@@ -1472,6 +1476,17 @@ struct Filter : FilterBase {
           const int* list = d_tilemap + solve6464_off + 2 * (2 * ntc - 2 * wt) * 2 * ntr;
           gemm<ROLE_SOLVE, true, 64, 64>(d_W + c0, ldy, Zs + c0, ldy, d_V + c0, ldy, npad_live + nb, width, width, T(1),
                                          T(0), 0, 0, 0, 1, 0, ss, list, 2 * wt * 2 * ntr);
+        } else if (kIsF32 && opt_mfma && !overlap && opt_solve_one_per_cu && wt * ntr < slots && wt * ntr > num_cus) {
+          // the last chunk's solve, alone on the chip, between one and two tiles of 128 x 128 per CU (N = 1000: 432 tiles with
+          // K = 128 .. 1152): ONE workgroup per CU drawing the tiles heaviest-first -- a workgroup that has its CU to itself
+          // runs a K step in 2.0 us against 3.2 us beside a second one, and with at most two per CU the heaviest tile bounds
+          // the launch either way; the light tiles then fill the CUs that finish first.  96 -> 86 us, bit-identical
+          // (round 4; 128 x 128 tiles on two workgroups per CU: 1.203 ms per step, 64 x 128 tiles: 1.149, this: 1.142)
+          solve_one_per_cu_now = true;
+          const int* list = d_tilemap + solve_off + 2 * (ntc - wt) * ntr;
+          gemm<ROLE_SOLVE, true>(d_W + c0, ldy, Zs + c0, ldy, d_V + c0, ldy, npad_live + nb, width, width, T(1), T(0), 0,
+                                 0, 0, 1, 0, ss, list, wt * ntr);
+          solve_one_per_cu_now = false;
         } else if (kIsF32 && opt_mfma && wt * ntr < slots) {     // narrow chunk: 64-row tiles fill the chip
           const int* list = d_tilemap + solve64_off + 2 * (ntc - wt) * 2 * ntr;
           gemm<ROLE_SOLVE, true, 64, 128>(d_W + c0, ldy, Zs + c0, ldy, d_V + c0, ldy, npad_live + nb, width, width, T(1),
