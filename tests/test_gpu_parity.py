@@ -703,6 +703,36 @@ def test_chunked_pipeline_matches_oracle(dtype, mfma, chunks):
     assert bound("mu, ref.mu #2", relf(mu, ref.mu), t["mu"] * 20) and bound("S, ref.Sigma #2", relf(S, ref.Sigma), t["S"] * 5)
 
 
+@pytest.mark.parametrize("recompute", [1, 0])
+def test_chunked_pipeline_with_subset_and_plane_rows_matches_oracle(recompute):
+    """The sequential form of the chunked update (EKF_OPT_W_RECOMPUTE, round 4) where its special cases meet: a measured
+    SUBSET (the runs of neighbouring features the LDS-staged W kernel looks for are broken: its per-workgroup fall-back),
+    the three plane rows (columns of W that are columns of the downdated Sigma) and the identity padding behind them, three
+    chunks forced on a map the oracle can follow -- against the fp32 oracle, with the right-looking W update (option 0)
+    beside it on the same inputs."""
+    ref, g = make_pair(210, np.float32)
+    g.set_option(3, 3)                                     # three chunks (m = 2 * 170 + 3: three block steps of 128)
+    g.set_option(7, recompute)
+    ref.predict()
+    g.predict()
+    vis = ref.visible_indices()
+    sel = [i for k, i in enumerate(vis) if k % 6 != 2][:170]      # gaps every sixth feature
+    z = o.synthetic_measurements(ref, sel, seed=31)
+    ref.update(z, sel, plane=True)
+    g.update(z, sel, plane_constraint=True)
+    g.synchronize()
+    mu, S = gpu_state(g)
+    t = TOL[np.float32]
+    # measured on the MI355X: 2.0e-6 / 5.0e-6 (re-evaluated W), 2.6e-6 / 5.3e-6 (right-looking W update)
+    assert bound("mu vs oracle", relf(mu, ref.mu), t["mu"] * 5)
+    assert bound("Sigma vs oracle", relf(S, ref.Sigma), t["S"] * 2)
+    assert np.array_equal(S, S.T)
+    pad, asym, big = g.checkInvariants()
+    assert pad == 0.0 and asym == 0.0
+    block, ends, wrec = g.chunkPlan()
+    assert block == 128 and ends == [1, 2, 3] and wrec == bool(recompute)
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_dynamic_resize_stream(dtype):
     """BASELINE configs[4] at oracle size: a measurement stream with features removed and added every few
