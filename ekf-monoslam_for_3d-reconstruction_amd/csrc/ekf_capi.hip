@@ -1187,9 +1187,9 @@ struct Filter : FilterBase {
       return env_nchunks;
     }
     if (opt_pipeline < 2) {
-      // default: three chunks ending at 3/16, 8/16 and 1 of the chain (tools/sweep_chunks.sh: the first chunk is
-      // exposed, so it is short; every further chunk re-reads Sigma once in its downdate, so there are few; with the
-      // chain at ~47 us per step the second stream, not the chain, decides where the last chunk may start)
+      // default: three chunks ending at 3/16, 7/16 (8/16 through round 3) and 1 of the chain: the first chunk is
+      // exposed, so it is short; every further chunk re-reads Sigma once in its downdate, so there are few; the chain and
+      // the second stream end together
       // Long chains (>= 32 steps; round 3, tools/knob_ab.py: 32 steps 6/16 -> 4/14: -1 %, 63 steps 12/32 -> 5/25: -2.6 %): the chain
       // is hidden there whatever the plan, so the first two chunks shrink in proportion -- less exposed start-up, and a
       // wider last chunk, whose downdate has every CU

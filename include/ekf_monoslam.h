@@ -82,7 +82,7 @@ enum ekf_option {
    * the solve then goes through the explicit inverse of the WHOLE factor, and Sigma after an update is an order of
    * magnitude further from the fp64 result than on the default path at 2M >= 2000 -- 1.2e-4 against 1.2e-5 of
    * max|Sigma|, tools/acc_check_sizes.py);
-   * 1 = the default three column chunks, the solve / W-update / downdate of every chunk but the last on a
+   * 1 = the default three column chunks, the solve / downdate / W re-evaluation (or update) of every chunk but the last on a
    * second, CU-masked stream beside the serial chain; k >= 2 = k equal chunks;
    * -1 (default): as 1 when the chain has at least 8 block steps (m >= 1024), else as 0. */
   EKF_OPT_PIPELINE = 3,
