@@ -14,7 +14,7 @@
 #include "../../include/ekf_monoslam.h"
 #include "ekf_dense.hpp"
 #include "ekf_image.hpp"
-#include "ekf_split.hpp"
+#include "ekf_syrk6.hpp"
 #include "ekf_kernels.hpp"
 #include "ekf_shard.hpp"
 
@@ -194,8 +194,8 @@ struct Filter : FilterBase {
   // that go out as 64 x 128 halves.  Measured at N = 1000: 384 halves 1.348 -> 1.329 ms (on the CU-masked side stream: no gain).
   int opt_split_tail = -1;
   double opt_feature_noise = 0.0;                       // EKF_OPT_FEATURE_NOISE: variance added to every feature state per predict
-  int opt_split_bf16 = 0;                               // EKF_OPT_SPLIT_BF16: downdate on the bf16 matrix pipe, 3 x bf16 per operand
-  __bf16* d_Vs[3] = {nullptr, nullptr, nullptr};
+  int opt_split_bf16 = 0;                               // EKF_OPT_SPLIT_BF16: downdate on the bf16 matrix pipe, 3 x bf16 per operand (ekf_syrk6.hpp)
+  s6_u32x4* d_Vimg = nullptr;                           // plane image of V: (n_pad + 128) / 128 row blocks x ldy / 16 records of 12 KB
   int last_nchunks = 1, last_cend[8] = {};
   // image side (8f4): current frame, templates (original / matching), blur-pose predictions, match results
   unsigned char* d_frame = nullptr;
@@ -256,7 +256,7 @@ struct Filter : FilterBase {
                     d_flags, d_cflag, d_Jy, d_Yxyz, d_map_src, d_map_conv, d_Y, d_W, d_V, d_Dinv, d_z, d_midx,
                     d_status, d_tmp, d_K, d_tilemap, d_counters, d_ibuf, d_rmask, d_pts, d_tab,
                     d_frame, d_patch[0], d_patch[1], d_mpatch[0], d_mpatch[1], d_hb, d_zm, d_found, d_score, d_keep,
-                    d_Vs[0], d_Vs[1], d_Vs[2], d_stage_send, d_stage_recv, d_archive, d_arch_idx, d_panel_tiles, d_shard_solve};
+                    d_Vimg, d_stage_send, d_stage_recv, d_archive, d_arch_idx, d_panel_tiles, d_shard_solve};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int s = 0; s < kInSlots; ++s) { if (h_in[s]) hipHostFree(h_in[s]); if (ev_in[s]) hipEventDestroy(ev_in[s]); }
     if (h_pred) hipHostFree(h_pred);
@@ -421,6 +421,7 @@ struct Filter : FilterBase {
       if (const char* e = getenv("EKF_FUSED_LAUNCHES")) opt_fused = atoi(e) ? 1 : 0;   // = EKF_OPT_FUSED_LAUNCHES, for A/B runs
       if (const char* e = getenv("EKF_PANEL_DIRECT")) opt_panel_direct = atoi(e);
       if (const char* e = getenv("EKF_SPLIT_TAIL")) opt_split_tail = atoi(e);
+      if (const char* e = getenv("EKF_SPLIT_BF16")) opt_split_bf16 = atoi(e) ? 1 : 0;   // = EKF_OPT_SPLIT_BF16, for A/B runs
       if (const char* e = getenv("EKF_CHUNKS")) {           // tuning knob: chunk ends in block steps
         for (const char* q = e; *q && env_nchunks < 8;) {
           env_chunks[env_nchunks++] = atoi(q);
@@ -1427,7 +1428,7 @@ struct Filter : FilterBase {
 
     // EKF_OPT_W_RECOMPUTE (fp32 MFMA path, several chunks): the W columns of chunk g + 1 come from the downdated Sigma
     // instead of the right-looking GEMM update (see the option's comment in ekf_monoslam.h)
-    const bool recompute = kIsF32 && opt_mfma && opt_wrecompute && nchunks > 1 && tile == 128 && !opt_split_bf16 && !oneblock;
+    const bool recompute = kIsF32 && opt_mfma && opt_wrecompute && nchunks > 1 && tile == 128 && !oneblock;
     int step = 0;
     bool b_inflight = false;
     for (int gi = 0; gi < nchunks; ++gi) {
@@ -1536,22 +1537,22 @@ struct Filter : FilterBase {
       }
       bool split_done = false;
       if constexpr (kIsF32) {
-        if (opt_split_bf16 && opt_mfma && tri_count >= num_cus && counter_next < 64) {
-          // opt-in: the same contraction on the bf16 matrix pipe, V_g split into three bf16 planes (ekf_split.hpp)
-          const size_t plane_elems = (size_t)(n_pad + 128) * ldy;
-          for (auto& pp : d_Vs)
-            if (!pp) HIPCHK(hipMalloc(&pp, plane_elems * sizeof(__bf16)));
+        if (opt_split_bf16 && opt_mfma && tile == 128 && tri_count >= num_cus && counter_next + 8 <= kQueueCounters) {
+          // EKF_OPT_SPLIT_BF16: the same contraction on the bf16 matrix pipe at fp32 accuracy (ekf_syrk6.hpp): V_g is split
+          // into the plane image (three bf16 per fp32, one 12 KB record per 128 rows x 16 columns), then the lower tiles
+          // of Sigma are downdated from LDS-DMA-fed records
+          if (!d_Vimg) HIPCHK(hipMalloc(&d_Vimg, (size_t)(n_pad + 128) * ldy * 6));
           {
             Scope sc(this, KID_MISC, ss);
-            dim3 grid((width + 255) / 256, npad_live);
-            k_split_bf16<<<grid, 256, 0, ss>>>(d_V, ldy, npad_live, c0, width, d_Vs[0], d_Vs[1], d_Vs[2]);
+            dim3 grid(npad_live / 128, width / 16);
+            k_split_image<<<grid, 256, 0, ss>>>(d_V, ldy, npad_live, c0, width, d_Vimg, ldy / 16);
           }
           Scope sc(this, KID_DOWNDATE, ss);
           if (sc.on) prof_work[KID_DOWNDATE] += double(n) * n * (std::min(c1, m) - std::min(c0, m));
-          SplitArgs a{{d_Vs[0] + c0, d_Vs[1] + c0, d_Vs[2] + c0}, ldy, S(), ld, width, d_tilemap, tri_count,
-                      d_counters + counter_next++};
+          Syrk6Args a{d_Vimg, ldy / 16, c0 / 16, width / 16, S(), ld, d_tilemap, tri_count, d_counters + counter_next, 2, 0, 0, 0};
+          counter_next += 8;
           const int wgs = 2 * (overlap ? (num_cus - reserved_cus) : num_cus);
-          k_syrk_bf16x3<<<std::min(tri_count, wgs), 256, 0, ss>>>(a);
+          k_syrk_bf16x6<0><<<std::min(tri_count, wgs), 256, 0, ss>>>(a);
           split_done = true;
         }
       }

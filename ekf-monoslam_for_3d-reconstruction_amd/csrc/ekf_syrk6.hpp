@@ -1,0 +1,262 @@
+// Covariance downdate Sigma -= V_g V_g^T (a10, vR.cpp:1279) on the bf16 matrix pipe at fp32 accuracy (round 5).
+//
+// Arithmetic (the one of ekf_split.hpp, round 1): an fp32 value is the exact sum of three bf16 values, a = a1 + a2 + a3;
+// of the nine bf16 x bf16 products of a * b the six above 2^-25 |a||b| -- below half an ulp of the fp32 product -- are
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16, smallest first: a3 b1, a1 b3, a2 b2, a2 b1, a1 b2, a1 b1.  Six of those
+// instructions retire 16 k in 192 cycles where v_mfma_f32_32x32x2_f32 needs 512: the fp32-equivalent peak of the scheme
+// is 2.5 PF / 6 = 417 TF against 157 TF of the fp32 instruction.
+//
+// What makes it run near that rate is the data path, which is built around the LDS-DMA (global_load_lds_dwordx4):
+//   * V_g is kept a second time as a PLANE IMAGE (k_split_image): per 128-row block and 16-column chunk one contiguous
+//     12 KB record [plane 3][k half 2][row 128][8 bf16] -- exactly the LDS image one operand of one K step needs, so a
+//     stage is filled by 1 KiB wave-instructions that are contiguous on both sides (no staging registers, no ds_write,
+//     full cache lines from L2);
+//   * a ring of three 24 KB stages (A record + B record): the loads of chunk s + 2 are issued right behind the barrier of
+//     step s and stay in flight across the next barrier (raw s_barrier + counted s_waitcnt vmcnt, never __syncthreads);
+//   * fragments by ds_read_b128 straight out of the record (lane = row, lane half = k half: conflict-free, no swizzle);
+//   * persistent grid on the same host-ordered tile lists as k_gemm_mfma (8 x 8 super-tiles, 64 x 128 half tiles at the
+//     end), two workgroups per CU; the ring runs ACROSS tiles: the first two chunks of the next tile are requested during
+//     the last two steps of this one and travel under the epilogue.
+// Sigma stays exactly symmetric: strictly-lower tiles are mirrored, diagonal tiles store their lower triangle twice.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ekf_dense.hpp"
+
+namespace ekf {
+
+typedef __bf16 s6_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int s6_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kS6Rec = 768;                    // 16-byte slots of one record (128 rows x 16 k x 3 planes x 2 B = 12 KB)
+
+// fp32 rows x width block of V (row-major, leading dimension ld, columns [c0, c0 + width)) -> plane image.
+// Image slot index of (row r, column c, plane p): ((r / 128) * nkc_total + c / 16) * 768 + p * 256 + ((c % 16) / 8) * 128 + r % 128.
+// One thread per (row, 8 columns): 32 B read, three 16-byte slots written (consecutive lanes = consecutive rows).
+__global__ void __launch_bounds__(256) k_split_image(const float* __restrict__ V, int ld, int rows, int c0, int width,
+                                                    s6_u32x4* __restrict__ img, int nkc_total) {
+  const int r = blockIdx.x * 128 + (threadIdx.x & 127);
+  const int o0 = blockIdx.y * 2 + (threadIdx.x >> 7);          // octet (8 columns) inside the launch
+  if (r >= rows || o0 * 8 >= width) return;
+  const int c = c0 + o0 * 8;
+  const float4 x0 = *reinterpret_cast<const float4*>(V + (size_t)r * ld + c);
+  const float4 x1 = *reinterpret_cast<const float4*>(V + (size_t)r * ld + c + 4);
+  const float a[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+  unsigned short p0[8], p1[8], p2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 a1 = (__bf16)a[e];
+    const float r1 = a[e] - (float)a1;
+    const __bf16 a2 = (__bf16)r1;
+    const float r2 = r1 - (float)a2;
+    const __bf16 a3 = (__bf16)r2;
+    p0[e] = __builtin_bit_cast(unsigned short, a1);
+    p1[e] = __builtin_bit_cast(unsigned short, a2);
+    p2[e] = __builtin_bit_cast(unsigned short, a3);
+  }
+  auto pack = [](const unsigned short* p) {
+    s6_u32x4 v = {(unsigned)p[0] | ((unsigned)p[1] << 16), (unsigned)p[2] | ((unsigned)p[3] << 16),
+                  (unsigned)p[4] | ((unsigned)p[5] << 16), (unsigned)p[6] | ((unsigned)p[7] << 16)};
+    return v;
+  };
+  s6_u32x4* rec = img + ((size_t)(r >> 7) * nkc_total + (c >> 4)) * kS6Rec + ((c >> 3) & 1) * 128 + (r & 127);
+  rec[0] = pack(p0);
+  rec[256] = pack(p1);
+  rec[512] = pack(p2);
+}
+
+struct Syrk6Args {
+  const s6_u32x4* img;   // plane image of V
+  int nkc_total;         // 16-column chunks per row block of the image (ldy / 16)
+  int kc0;               // first chunk of this launch (c0 / 16)
+  int nk;                // chunks of this launch (chunk width / 16), >= 2
+  float* C; int ldc;     // Sigma
+  const int* tile_map; int ntiles; int* counter;   // (bi, bj) list as for k_gemm_mfma<ROLE_DOWNDATE>: kHalfTile / kMirrorTile on bi
+  int tri;               // 2: lower tiles, strictly-lower ones mirrored; 3: every listed tile, kMirrorTile ones mirrored
+  int row_off, col_off;  // tri 3 (row panel of a rank): global row / column of C's local (0, 0)
+  int a_rb0;             // row block of the image that holds local row 0 of A (tri 3); B blocks are global
+};
+
+// ABL (tools/syrk6_probe.hip only): 1 = no C traffic (the accumulators are kept live), 2 = no LDS-DMA (the ring keeps what it
+// has), 4 = every LDS-DMA reads the first record (always cache hits)
+template <int ABL = 0>
+__global__ void __launch_bounds__(256, 2) k_syrk_bf16x6(Syrk6Args g) {
+  constexpr int NS = 3, STG = 2 * kS6Rec;                      // ring stages; slots per stage (A record + B record)
+  __shared__ s6_u32x4 lds[NS * STG + 1];                       // ONE LDS object (the last slot: the queue's hand-over words)
+  int* const s_next = reinterpret_cast<int*>(&lds[NS * STG]);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1, h = lane >> 5, l31 = lane & 31;
+  float* const C = g.C;
+  const int ldc = g.ldc;
+  const int nk = g.nk;                                         // even, >= 8 (host)
+
+  struct Tile { int rbA, rbB, arow, half, bj, mirror, diag; };
+  auto decode = [&](int rbi, int rbj) {
+    Tile t;
+    const bool lm = (rbi & kMirrorTile) != 0;
+    t.half = (rbi & kHalfTile) ? 1 : 0;
+    const int bi = rbi & 0xffff;
+    t.bj = rbj & 0xffff;
+    t.arow = t.half ? bi * 64 : bi * 128;                      // first local row of the tile (A and C)
+    t.rbA = g.a_rb0 + (t.arow >> 7);
+    t.rbB = t.bj;
+    const int grow0 = g.row_off + t.arow, gcol0 = g.col_off + t.bj * 128;
+    t.mirror = ((g.tri == 2 && grow0 >= gcol0 + 128) || (g.tri == 3 && lm)) ? 1 : 0;
+    t.diag = (g.tri == 2 && (grow0 >> 7) == (gcol0 >> 7)) ? 1 : 0;
+    return t;
+  };
+  // chunk c of tile t -> ring stage st: 24 pieces of 1 KiB, six per wave (pieces 0-11: A record, 12-23: B record)
+  auto issue = [&](const Tile& t, int c, int st) {
+    if (ABL & 2) return;
+    const s6_u32x4* ra = g.img + ((ABL & 4) ? (size_t)0 : ((size_t)t.rbA * g.nkc_total + g.kc0 + c) * kS6Rec);
+    const s6_u32x4* rb = g.img + ((ABL & 4) ? (size_t)0 : ((size_t)t.rbB * g.nkc_total + g.kc0 + c) * kS6Rec);
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int pc = wave + 4 * u;                             // u < 3: A pieces, u >= 3: B pieces
+      const s6_u32x4* src = (u < 3 ? ra + pc * 64 : rb + (pc - 12) * 64) + lane;
+      s6_u32x4* dst = lds + st * STG + pc * 64;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+  // ---- first tile -----------------------------------------------------------------------------------------------------
+  if (tid == 0) {
+    const int t = atomicAdd(g.counter, 1);
+    s_next[0] = t < g.ntiles ? g.tile_map[2 * t] : -1;
+    s_next[1] = t < g.ntiles ? g.tile_map[2 * t + 1] : 0;
+  }
+  __syncthreads();
+  int raw_i = __builtin_amdgcn_readfirstlane(s_next[0]), raw_j = __builtin_amdgcn_readfirstlane(s_next[1]);
+  if (raw_i < 0) return;
+  Tile cur = decode(raw_i, raw_j);
+  int st = 0;                                                  // ring stage of the current chunk
+  issue(cur, 0, 0);
+  issue(cur, 1, 1);
+  bool have = true, post_epi = false;
+
+  while (have) {
+    const Tile t = cur;
+    Tile nxt = t;
+    bool have_next = false;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    int ticket = 0;
+    // The next list entry is drawn while this tile computes: thread 0 takes a ticket at step claim_at, the entry is looked up
+    // and handed over through LDS at step pub_at, everybody reads it at step nk - 3 (the barriers of the steps in between
+    // order it) and requests the next tile's first two chunks in the last two steps.
+    const int claim_at = nk > 14 ? nk - 14 : 0;
+    const int pub_at = min(claim_at + 5, nk - 5);
+    // the C tile, requested in step nk - 2 (behind that step's LDS-DMA pieces) and used in the epilogue
+    float cv[2][2][16];
+    const int rb0 = t.arow + wr * 64 + 4 * h, cb0 = t.bj * 128 + wc * 64 + l31;
+    for (int s = 0; s < nk; ++s) {
+      // chunk s has landed (this wave's pieces); chunk s + 1 may be in flight -- and, in the last step, the 64 loads of the
+      // C tile behind it; behind a tile's epilogue its stores (at least 64 per lane, younger than the chunks under way)
+      const bool more1 = (s + 1 < nk) || have_next;
+      if ((s < 2 && post_epi) || s == nk - 1) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+      else if (more1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                            // everybody's pieces of chunk s; everybody is out of stage st - 1
+      __builtin_amdgcn_sched_barrier(0);
+      const int st2 = (st == 0) ? 2 : st - 1;                  // (st + 2) % 3
+      if (s + 2 < nk) issue(t, s + 2, st2);
+      else if (have_next) issue(nxt, s + 2 - nk, st2);
+      if (s == nk - 2 && !(ABL & 1)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float* Cp = C + (size_t)(rb0 + i * 32) * ldc + cb0 + j * 32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) cv[i][j][e] = Cp[(size_t)((e & 3) + 8 * (e >> 2)) * ldc];
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // fragments of this chunk: lane = row, lane half = k half (conflict-free ds_read_b128, no swizzle)
+      const s6_u32x4* Sa = lds + st * STG + h * 128 + wr * 64 + l31;
+      const s6_u32x4* Sb = lds + st * STG + kS6Rec + h * 128 + wc * 64 + l31;
+      s6_bf16x8 fa[3][2], fb[3][2];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          fa[p][i] = __builtin_bit_cast(s6_bf16x8, Sa[p * 256 + i * 32]);
+          fb[p][i] = __builtin_bit_cast(s6_bf16x8, Sb[p * 256 + i * 32]);
+        }
+      // smallest products first: a3 b1, a1 b3, a2 b2, a2 b1, a1 b2, a1 b1
+      constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA_[q]][i], fb[PB_[q]][j], acc[i][j], 0, 0, 0);
+      // queue hand-over (thread 0)
+      if (s == claim_at) {
+        if (tid == 0) ticket = atomicAdd(g.counter, 1);
+      } else if (s == pub_at) {
+        if (tid == 0) {
+          s_next[0] = ticket < g.ntiles ? g.tile_map[2 * ticket] : -1;
+          s_next[1] = ticket < g.ntiles ? g.tile_map[2 * ticket + 1] : 0;
+        }
+      } else if (s == nk - 3) {
+        raw_i = __builtin_amdgcn_readfirstlane(s_next[0]);
+        raw_j = __builtin_amdgcn_readfirstlane(s_next[1]);
+        have_next = raw_i >= 0;
+        if (have_next) nxt = decode(raw_i, raw_j);
+      }
+      st = (st + 1 == NS) ? 0 : st + 1;
+    }
+    post_epi = true;
+    // ---- epilogue: C' = C - acc (one rounding at the magnitude of C), mirror ---------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (ABL & 1) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc[i][j][e]));
+          continue;
+        }
+        const int rbase = t.arow + wr * 64 + i * 32;
+        const int c = cb0 + j * 32;
+        float* Cp = C + (size_t)(rbase + 4 * h) * ldc + c;
+        float v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = cv[i][j][e] - acc[i][j][e];
+        if (t.diag) {
+          // diagonal tile: (r, c) and (c, r) add the same six products in a different order; Sigma stays exactly symmetric
+          // by storing the lower triangle and its mirror
+          const int gr0 = g.row_off + rbase + 4 * h, gc = g.col_off + c;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int dr = (e & 3) + 8 * (e >> 2);
+            if (gr0 + dr >= gc) {
+              Cp[(size_t)dr * ldc] = v[e];
+              C[(size_t)(gc - g.row_off) * ldc + (gr0 + dr - g.col_off)] = v[e];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) Cp[(size_t)((e & 3) + 8 * (e >> 2)) * ldc] = v[e];
+          if (t.mirror) {
+            float* Ct = C + (size_t)(c + g.col_off - g.row_off) * ldc + (g.row_off - g.col_off);
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+              f32x4 o = {v[4 * gq], v[4 * gq + 1], v[4 * gq + 2], v[4 * gq + 3]};
+              *reinterpret_cast<f32x4*>(Ct + rbase + 8 * gq + 4 * h) = o;
+            }
+          }
+        }
+      }
+    have = have_next;
+    cur = nxt;
+  }
+}
+
+}  // namespace ekf
