@@ -59,6 +59,7 @@ static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
 struct FilterBase {
   std::string err;
+  bool diag_synced = false;   // sharded filter: the owners' diagonal blocks were gathered and nothing changed Sigma or the layout since (shard_sync_diag_blocks)
   virtual ~FilterBase() {}
   virtual int set_dt(double) = 0;
   virtual double get_dt() const = 0;
@@ -221,7 +222,6 @@ struct Filter : FilterBase {
   int opt_fused = 1;                                    // EKF_OPT_FUSED_LAUNCHES: k_predict_fused, k_solve_state_oneblock, k_update_oneblock_small
   int opt_solve_one_per_cu = 1;                         // EKF_SOLVE_ONE_PER_CU: the last solve on one workgroup per CU when it has 1 .. 2 tiles per CU
   bool solve_one_per_cu_now = false;
-  int opt_lazy_trailing = 0;                            // EKF_LAZY_TRAILING=1 (opt-in, A/B): the chain's trailing update stays inside the chunk, one deferred update per chunk
   int opt_wrecompute = 1;                               // EKF_OPT_W_RECOMPUTE / EKF_W_RECOMPUTE: next chunk's W re-evaluated from the downdated Sigma
   int opt_fuse_wu = 1;                                  // EKF_FUSE_WU: 0 never, 1 every overlapped chunk but the one before the last, 2 every overlapped chunk
   int env_chunks[8] = {}, env_nchunks = 0;               // EKF_CHUNKS="5,10,14,16": tuning knob (block steps)
@@ -415,7 +415,6 @@ struct Filter : FilterBase {
       }
       if (const char* e = getenv("EKF_FUSE_WU")) opt_fuse_wu = atoi(e);
       if (const char* e = getenv("EKF_SOLVE_ONE_PER_CU")) opt_solve_one_per_cu = atoi(e) ? 1 : 0;
-      if (const char* e = getenv("EKF_LAZY_TRAILING")) opt_lazy_trailing = atoi(e) ? 1 : 0;
       if (const char* e = getenv("EKF_W_RECOMPUTE")) opt_wrecompute = atoi(e) ? 1 : 0;   // = EKF_OPT_W_RECOMPUTE, for A/B runs
       if (const char* e = getenv("EKF_SOLVE_S2")) opt_solve_s2 = atoi(e);
       if (const char* e = getenv("EKF_FUSED_LAUNCHES")) opt_fused = atoi(e) ? 1 : 0;   // = EKF_OPT_FUSED_LAUNCHES, for A/B runs
@@ -799,6 +798,7 @@ struct Filter : FilterBase {
     // sharded: the 3 x 3 block of a removed feature is valid on its owner only -- gathered first, so that every rank
     // archives the same 12 scalars (the list above is the same on every rank: host metadata is replicated)
     int rc = shard_sync_diag_blocks();
+    diag_synced = false;                                     // the removal that follows compacts Sigma
     if (rc) return rc;
     const size_t have = arch_real.size(), need = have + ap.size();
     if (need > arch_cap) {
@@ -1317,13 +1317,7 @@ struct Filter : FilterBase {
         T* P = Y + (size_t)r0 * ldy + j;
         launch_panel(P, Dj, vrows, sc_);
       }
-      // EKF_LAZY_TRAILING=1 (round 4, NOT the default): inside a chunk the trailing update only covers the columns of THAT
-      // chunk (what its own steps read); the columns of the later chunks get ONE rank-(chunk width) update when the chain
-      // leaves the chunk (chain_deferred): a third of the tiles per step, 1.153 -> 1.144 ms at N = M = 1000 -- and Sigma
-      // twice as far from the fp64 oracle (frame 1: 5.1e-5 against 2.2e-5, tools/acc_knobs.py): S cancels by orders of
-      // magnitude under the first block columns, and products added to an accumulator that still holds the whole sum are
-      // rounded at ITS magnitude; the step-by-step update rounds each rank-128 term against the already reduced S
-      const int tcols = (opt_lazy_trailing && c1 < m_pad) ? c1 - r0 : m_pad - r0;
+      const int tcols = m_pad - r0;
       if (r0 < m_pad && tcols > 0) {
         Scope sc(this, KID_CHOL_TRAILING, sc_);              // Y[r0.., r0:] -= P P_S^T; strip rows stop at c1
         const T* P = Y + (size_t)r0 * ldy + j;
@@ -1333,18 +1327,6 @@ struct Filter : FilterBase {
       }
     }
   }
-  // ... and the update of the later chunks' columns the steps of chunk [c0, c1) left out (EKF_LAZY_TRAILING): launched
-  // AFTER the event that tells the second stream the chunk is factored -- its solve does not read those columns
-  void chain_deferred(int c0, int c1, int m_pad, hipStream_t sc_) {
-    if (!opt_lazy_trailing || c1 >= m_pad || c1 <= c0) return;
-    T* Y = d_Y;
-    Scope sc(this, KID_CHOL_TRAILING, sc_);                  // Y[c1.., c1..] -= P_g P_g^T, P_g = L[c1.., c0:c1): lower tiles
-    const T* P = Y + (size_t)c1 * ldy + c0;
-    T* C = Y + (size_t)c1 * ldy + c1;
-    gemm<ROLE_TRAILING, false, 64, 64>(P, ldy, P, ldy, C, ldy, m_pad - c1, m_pad - c1, c1 - c0, T(-1), T(1), 1, c1, c1, 0, 0,
-                                       sc_);
-  }
-
   // ---- a8-a11 update ---------------------------------------------------------------------
   int update(const void* z, const int* idx, int M, int plane, bool on_device) override {
     HIPCHK(hipSetDevice(device));
@@ -1455,7 +1437,6 @@ struct Filter : FilterBase {
         HIPCHK(hipEventRecord(ev_chain[gi], sc_));
         HIPCHK(hipStreamWaitEvent(stream_b, ev_chain[gi], 0));
       }
-      chain_deferred(c0, c1, m_pad, sc_);
       if (oneblock) {
         if constexpr (kIsF32) {
           const int nrb = npad_live / 64, nt64 = nrb * (nrb + 1) / 2;
@@ -2243,9 +2224,15 @@ struct Filter : FilterBase {
   // as a plain 2-D grid of 128 x 128 tiles, whose static placement pairs the heavy tiles of a column on the same CUs:
   // 0.50 ms of solves per step at N = 1000 / world 1 against 0.16 on the plain path.
   int* d_shard_solve = nullptr;
-  int shard_solve_nrt = 0, shard_solve_ntc = 0;
-  int ensure_shard_solve_list(int nrt, int ntc) {
-    if (nrt == shard_solve_nrt && ntc == shard_solve_ntc) return EKF_OK;
+  int shard_solve_nrt = 0;
+  int shard_ntc_max() const { return ldy / 128; }
+  // The list covers every column tile the workspace can hold (ldy / 128), last column tile first; a chunk of wt column tiles
+  // starts at entry (ntc_max - wt) * nrt (the entries are relative to the chunk: bj = wt - 1 .. 0), so the list depends on
+  // the number of row tiles only -- it is rebuilt (streams drained) when the panel of the rank changes its height, never
+  // because M crossed a multiple of 64
+  int ensure_shard_solve_list(int nrt) {
+    if (nrt == shard_solve_nrt) return EKF_OK;
+    const int ntc = shard_ntc_max();
     std::vector<int> tl;
     tl.reserve((size_t)2 * nrt * ntc);
     for (int j = ntc - 1; j >= 0; --j)
@@ -2254,11 +2241,10 @@ struct Filter : FilterBase {
     if (stream_b) HIPCHK(hipStreamSynchronize(stream_b));
     if (d_shard_solve) HIPCHK(hipFree(d_shard_solve));
     d_shard_solve = nullptr;
-    shard_solve_nrt = shard_solve_ntc = 0;
+    shard_solve_nrt = 0;
     HIPCHK(hipMalloc(&d_shard_solve, tl.size() * sizeof(int)));
     HIPCHK(hipMemcpy(d_shard_solve, tl.data(), tl.size() * sizeof(int), hipMemcpyHostToDevice));
     shard_solve_nrt = nrt;
-    shard_solve_ntc = ntc;
     return EKF_OK;
   }
 
@@ -2304,6 +2290,9 @@ struct Filter : FilterBase {
   // which the next gather of those rows overwrites).  A COLLECTIVE: every rank makes the call.
   int shard_sync_diag_blocks() {
     if (!sh_on || !exchanges() || N == 0) return EKF_OK;
+    // repeated map getters between two filter steps cost ONE collective: every entry point that changes mu, Sigma or the
+    // layout clears the flag (the C wrappers below), on every rank alike -- the getters stay collective calls all the same
+    if (diag_synced) return EKF_OK;
     int rc = sync_layout();
     if (rc) return rc;
     const ShardTab tab = feature_tab();
@@ -2319,6 +2308,7 @@ struct Filter : FilterBase {
     if (rc) return rc;
     k_unpack_diag<T><<<dim3((36 * mx + 255) / 256, sh_world), 256, 0, stream>>>(d_stage_recv, slot, S(), ld, d_pos, d_coding, tab);
     HIPCHK(hipGetLastError());
+    diag_synced = true;
     return EKF_OK;
   }
   // raw bytes of every rank (own_bytes <= slot_bytes each) -> host buffer of world x slot_bytes
@@ -2744,7 +2734,6 @@ struct Filter : FilterBase {
         HIPCHK(hipEventRecord(ev_b, stream_b));
         HIPCHK(hipStreamWaitEvent(stream, ev_b, 0));
       }
-      chain_deferred(c0, c1, m_pad, stream);
       for (int q = 0; q < 3; ++q) {
         const Rows& rr = ranges[q];
         if (rr.count == 0) continue;
@@ -2756,9 +2745,9 @@ struct Filter : FilterBase {
           if (q == 1 && opt_mfma && nb == 128 && counter_next + 8 <= kQueueCounters) {
             // the own panel: 64 x 128 tiles drawn heaviest-first from a work queue (what the plain path does)
             const int nrt = rr.count / 64, wt = width / 128;
-            rc = ensure_shard_solve_list(nrt, m_pad / 128);
+            rc = ensure_shard_solve_list(nrt);
             if (rc) return rc;
-            const int* list = d_shard_solve + 2 * (m_pad / 128 - wt) * nrt;
+            const int* list = d_shard_solve + 2 * (shard_ntc_max() - wt) * nrt;
             gemm<ROLE_SOLVE, true, 64, 128>(d_W + off + c0, ldy, Zs + c0, ldy, d_V + off + c0, ldy, rr.count, width, width, T(1),
                                             T(0), 0, 0, 0, 1, 0, ss, list, wt * nrt);
             queued = true;
@@ -2971,22 +2960,24 @@ const char* ekf_last_error(const ekf_filter* f) {
 
 #define IMPL_OR_ARG(f) \
   if (!(f)) return EKF_ERR_ARG
+// entry points that change mu, Sigma, the layout or the sharding: the gathered diagonal blocks are stale afterwards
+#define MUTATES(f) (f)->impl->diag_synced = false
 
 int ekf_set_dt(ekf_filter* f, double dT) { IMPL_OR_ARG(f); return f->impl->set_dt(dT); }
 double ekf_get_dt(const ekf_filter* f) { return f ? f->impl->get_dt() : 0.0; }
 int ekf_set_stream(ekf_filter* f, void* s) { IMPL_OR_ARG(f); return f->impl->set_stream(s); }
-int ekf_set_option(ekf_filter* f, int o, int v) { IMPL_OR_ARG(f); return f->impl->set_option(o, v); }
+int ekf_set_option(ekf_filter* f, int o, int v) { IMPL_OR_ARG(f); MUTATES(f); return f->impl->set_option(o, v); }
 int ekf_synchronize(ekf_filter* f) { IMPL_OR_ARG(f); return f->impl->synchronize(); }
 
-int ekf_add_feature(ekf_filter* f, double u, double v) { if (!f) return -EKF_ERR_ARG; return f->impl->add_feature(u, v); }
-int ekf_remove_feature(ekf_filter* f, int index) { IMPL_OR_ARG(f); return f->impl->remove_features(&index, 1); }
+int ekf_add_feature(ekf_filter* f, double u, double v) { if (!f) return -EKF_ERR_ARG; MUTATES(f); return f->impl->add_feature(u, v); }
+int ekf_remove_feature(ekf_filter* f, int index) { IMPL_OR_ARG(f); MUTATES(f); return f->impl->remove_features(&index, 1); }
 int ekf_remove_features(ekf_filter* f, const int* idx, int count) {
-  IMPL_OR_ARG(f);
+  IMPL_OR_ARG(f); MUTATES(f);
   if (count > 0 && !idx) return EKF_ERR_ARG;
   return f->impl->remove_features(idx, count);
 }
 
-int ekf_predict(ekf_filter* f, const void* t, const void* r, int vc) { IMPL_OR_ARG(f); return f->impl->predict(t, r, vc); }
+int ekf_predict(ekf_filter* f, const void* t, const void* r, int vc) { IMPL_OR_ARG(f); MUTATES(f); return f->impl->predict(t, r, vc); }
 int ekf_measure(ekf_filter* f) { IMPL_OR_ARG(f); return f->impl->measure(); }
 int ekf_get_motion_jacobian(ekf_filter* f, void* Ft, void* Q) { IMPL_OR_ARG(f); return f->impl->motion_jacobian(Ft, Q); }
 int ekf_get_predictions(ekf_filter* f, void* h, unsigned char* vis, unsigned char* rem, void* s2, void* hc, void* hf) {
@@ -2994,11 +2985,11 @@ int ekf_get_predictions(ekf_filter* f, void* h, unsigned char* vis, unsigned cha
   return f->impl->get_predictions(h, vis, rem, s2, hc, hf);
 }
 int ekf_update(ekf_filter* f, const void* z, const int* idx, int M, int plane) {
-  IMPL_OR_ARG(f);
+  IMPL_OR_ARG(f); MUTATES(f);
   return f->impl->update(z, idx, M, plane, false);
 }
 int ekf_update_device(ekf_filter* f, const void* dz, const int* didx, int M, int plane) {
-  IMPL_OR_ARG(f);
+  IMPL_OR_ARG(f); MUTATES(f);
   return f->impl->update(dz, didx, M, plane, true);
 }
 int ekf_innovation_covariance(ekf_filter* f, const int* idx, int M, int plane, void* out) {
@@ -3009,22 +3000,22 @@ int ekf_innovation_covariance(ekf_filter* f, const int* idx, int M, int plane, v
 int ekf_get_gain(ekf_filter* f, void* out) { IMPL_OR_ARG(f); if (!out) return EKF_ERR_ARG; return f->impl->get_gain(out); }
 int ekf_last_measurement_rows(const ekf_filter* f) { return f ? f->impl->last_rows() : 0; }
 
-int ekf_convert_xyz_if_linear(ekf_filter* f, int index) { if (!f) return -EKF_ERR_ARG; return f->impl->convert(index, false); }
-int ekf_convert_xyz_if_linear_all(ekf_filter* f) { if (!f) return -EKF_ERR_ARG; return f->impl->convert(0, true); }
+int ekf_convert_xyz_if_linear(ekf_filter* f, int index) { if (!f) return -EKF_ERR_ARG; MUTATES(f); return f->impl->convert(index, false); }
+int ekf_convert_xyz_if_linear_all(ekf_filter* f) { if (!f) return -EKF_ERR_ARG; MUTATES(f); return f->impl->convert(0, true); }
 
 int ekf_num_features(const ekf_filter* f) { return f ? f->impl->num_features() : 0; }
 int ekf_state_dim(const ekf_filter* f) { return f ? f->impl->state_dim() : 0; }
 int ekf_get_feature_layout(const ekf_filter* f, int* p, int* c) { IMPL_OR_ARG(f); return f->impl->get_layout(p, c); }
 
 int ekf_get_state(ekf_filter* f, void* out, int off, int cnt) { IMPL_OR_ARG(f); if (cnt > 0 && !out) return EKF_ERR_ARG; return f->impl->get_state(out, off, cnt); }
-int ekf_set_state(ekf_filter* f, const void* in, int off, int cnt) { IMPL_OR_ARG(f); if (cnt > 0 && !in) return EKF_ERR_ARG; return f->impl->set_state(in, off, cnt); }
+int ekf_set_state(ekf_filter* f, const void* in, int off, int cnt) { IMPL_OR_ARG(f); MUTATES(f); if (cnt > 0 && !in) return EKF_ERR_ARG; return f->impl->set_state(in, off, cnt); }
 int ekf_get_sigma_block(ekf_filter* f, void* out, int r0, int c0, int rows, int cols) {
   IMPL_OR_ARG(f);
   if (!out) return EKF_ERR_ARG;
   return f->impl->get_sigma(out, r0, c0, rows, cols);
 }
 int ekf_set_sigma_block(ekf_filter* f, const void* in, int r0, int c0, int rows, int cols) {
-  IMPL_OR_ARG(f);
+  IMPL_OR_ARG(f); MUTATES(f);
   if (!in) return EKF_ERR_ARG;
   return f->impl->set_sigma(in, r0, c0, rows, cols);
 }
@@ -3074,20 +3065,20 @@ int ekf_ransac_1point(ekf_filter* f, const void* z, const int* idx, int M, doubl
 }
 int ekf_update_two_stage(ekf_filter* f, const void* z, const int* idx, int M, int plane, unsigned int seed,
                          double thr, double chi2, unsigned char* is_li, unsigned char* is_hi, int* drawn) {
-  IMPL_OR_ARG(f);
+  IMPL_OR_ARG(f); MUTATES(f);
   if (M > 0 && (!z || !idx)) return EKF_ERR_ARG;
   return f->impl->update_two_stage(z, idx, M, plane, seed, thr, chi2, is_li, is_hi, drawn);
 }
 int ekf_shard_configure(ekf_filter* f, int rank, int world, ekf_allgather_fn fn, void* ctx) {
-  IMPL_OR_ARG(f);
+  IMPL_OR_ARG(f); MUTATES(f);
   return f->impl->shard_configure(rank, world, fn, ctx);
 }
 int ekf_shard_get_info(ekf_filter* f, ekf_shard_info* out) { IMPL_OR_ARG(f); return f->impl->shard_info(out); }
 int ekf_shard_update(ekf_filter* f, const void* dz, const int* idx, int M, int plane) {
-  IMPL_OR_ARG(f);
+  IMPL_OR_ARG(f); MUTATES(f);
   return f->impl->shard_update(dz, idx, M, plane);
 }
-int ekf_shard_rebalance(ekf_filter* f) { IMPL_OR_ARG(f); return f->impl->shard_rebalance(); }
+int ekf_shard_rebalance(ekf_filter* f) { IMPL_OR_ARG(f); MUTATES(f); return f->impl->shard_rebalance(); }
 
 void* ekf_device_mu(ekf_filter* f) { return f ? f->impl->dev_mu() : nullptr; }
 void* ekf_device_sigma(ekf_filter* f, int* ld) { return f ? f->impl->dev_sigma(ld) : nullptr; }

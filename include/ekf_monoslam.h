@@ -324,8 +324,12 @@ const char* ekf_profile_kernel_name(int kernel_id);
 int ekf_profile_read(ekf_filter* f, int kernel_id, double* total_ms, long long* launches);
 int ekf_profile_reset(ekf_filter* f);
 /* Algorithmic flop of the launches timed under `kernel_id` since the last reset (kept for "downdate_syrk" only:
- * n^2 x the real columns of the chunk (symmetric half), plus 2 (n+1) (m - c1) x those columns where the launch also
- * carries the W update of its chunk). */
+ * n^2 x the real columns of the chunk (symmetric half).  Where the launch also carries a right-looking update of its
+ * chunk -- exact-fp32 path, EKF_FUSE_WU -- that product is counted with it: under EKF_OPT_W_RECOMPUTE = 1 (the default)
+ * only the innovation ROW is updated, 2 x 1 x (m - c1) x the chunk's columns; under = 0 the whole W, 2 (n + 1) (m - c1)
+ * x those columns).  Where the other pieces of the sequential form are booked: the re-evaluation W'_h = Sigma' H_h^T under
+ * "sigma_ht", a NON-fused innovation-row update (EKF_FUSE_WU = 0, EKF_OPT_SPLIT_BF16 = 1) under "w_update", the plane
+ * image of V_g (EKF_OPT_SPLIT_BF16 = 1) under "misc". */
 int ekf_profile_work(ekf_filter* f, int kernel_id, double* flop);
 /* How the last ekf_update factored S (what the algorithmic flop of a step depends on): `block` = rows of a block step
  * (128 fp32 MFMA, 64 otherwise), ends[g] = block step at which column chunk g ends (the last one = m_pad / block),
@@ -392,7 +396,11 @@ typedef struct ekf_shard_info {
  *   first of these calls after a predict is the collective one -- make the same calls on every rank),
  *   ekf_find_matches (the same 2x2 blocks),
  *   ekf_feature_xyz, ekf_export_points, ekf_export_points_table (round 4: a feature's covariance block is valid on
- *   its owner only; the owners' diagonal blocks are all-gathered first, so every rank returns the same table).
+ *   its owner only; the owners' diagonal blocks are all-gathered first, so every rank returns the same table.  Round 5:
+ *   the gathered blocks stay valid until the next call that changes mu, Sigma, the layout or the sharding (predict, the
+ *   updates, add / remove / convert, the setters, re-balance, ekf_set_option), so a loop of N per-feature getters between
+ *   two filter steps costs ONE all-gather, not N -- the first getter after such a call is the collective one, as for the
+ *   2x2 blocks above: make the same getter calls on every rank, or none).
  * Local (no exchange): ekf_add_feature, ekf_get_state, ekf_get_sigma_block (valid for camera + own rows),
  * ekf_get_predictions without s2, ekf_covariance_parameter, ekf_shard_get_info, the setters, ekf_last_error. */
 int ekf_shard_configure(ekf_filter* f, int rank, int world, ekf_allgather_fn allgather, void* ctx);
