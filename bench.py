@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_F32_MFMA_TF = 157.3     # MI355X_MICROARCH.md: f32-input MFMA = vector peak
+PEAK_BF16_MFMA_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (~2.5 PF; the 5 PF headline includes 2:1 sparsity)
 SIGMA_Z_PX = 0.5              # pixel noise of the synthetic stream (the filter's R stays sigma_pixel^2 = 4)
 
 
@@ -56,11 +57,15 @@ def parse():
     ap.add_argument("--cpu-full", action="store_true",
                     help="also time ONE frame of the dense formulation on a single thread (minutes at N = 1000; for profiles/)")
     ap.add_argument("--pipeline", type=int, default=-1, help="EKF_OPT_PIPELINE (overlap chain with solve/downdate pieces)")
-    ap.add_argument("--secondary-split-bf16", action="store_true",
-                    help="also run the secondary pass with EKF_OPT_SPLIT_BF16 (an opt-in variant; not part of the default run)")
-    ap.add_argument("--split-bf16", action="store_true",
-                    help="EKF_OPT_SPLIT_BF16: downdate on the bf16 matrix pipe, fp32 operands split 3 x bf16 (NOT the default "
-                         "and not the headline: the line then says so in `dtype` and `config`)")
+    ap.add_argument("--exact-fp32", action="store_true",
+                    help="EKF_OPT_SPLIT_BF16 = 0: every contraction on v_mfma_f32_32x32x2_f32 (the round 1-4 arithmetic).  The default "
+                         "(round 5) runs the covariance downdate of large maps on the bf16 matrix pipe at fp32 accuracy: each "
+                         "fp32 operand split exactly into 3 bf16, the six products above 2^-25 |a||b| accumulated in fp32")
+    ap.add_argument("--no-secondary-exact-fp32", action="store_true",
+                    help="skip the short secondary pass that times the same steps with EKF_OPT_SPLIT_BF16 = 0")
+    ap.add_argument("--resize-every", type=int, default=0,
+                    help="configs[4] cadence: every K frames remove 1 %% of the features and add as many (SURVEY 8d); adds a "
+                         "`resize` object (ms per event, compaction GB/s, add cost per feature) from a separate pass")
     return ap.parse_args()
 
 
@@ -209,6 +214,82 @@ def cpu_baseline(cfg_name, n_feat, px0, zs, threads, full=False):
     return out
 
 
+def resize_pass(pkg, cfg, n_feat, px0, z, args):
+    """configs[4] cadence on ONE GPU: every `--resize-every` frames 1 % of the features are removed (uniform
+    indices, seed 1236, one call: the library removes in descending order as vR.cpp:1296 does) and as many are added
+    (vR.cpp:309-371, one ekf_add_feature each); the new features are never measured (no stream behind them).  Wall time of
+    the two halves of an event between synchronisations, and the kernels behind them from the library's HIP events:
+    k_compact_transform (vR.cpp:373-421: Sigma read once and written once into the second buffer, 2 n^2 s algorithmic
+    bytes) and k_add_prepare + k_add_border (vR.cpp:309-371: an O(n) border per feature)."""
+    every = args.resize_every
+    frames = min(len(z), args.warmup + args.steps)
+    flt = build_filter(pkg, cfg, n_feat, px0)
+    rng = np.random.default_rng(1236)
+    sid = np.arange(n_feat)
+    t_rm, t_add, n_rm = [], [], []
+    kern = {}
+    t_steps = 0.0
+    for k in range(frames):
+        t0 = time.perf_counter()
+        flt.predict()
+        h, vis, rem, _ = flt.predictions()
+        sel = np.nonzero(vis.astype(bool) & (sid >= 0))[0].astype(np.int32)
+        flt.update(z[k][sid[sel]].reshape(-1), sel)
+        if (k + 1) % every == 0:
+            flt.synchronize()
+            t_steps += time.perf_counter() - t0
+            N = flt.numOfFeatures()
+            n_state = flt.stateDim()
+            drop = sorted(rng.choice(N, size=max(1, N // 100), replace=False).tolist())
+            flt.set_option(2, 2)
+            flt.profile_reset()
+            t1 = time.perf_counter()
+            flt.removeFeatures(drop)
+            flt.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(len(drop)):
+                assert flt.addFeature((float(rng.uniform(20, 300)), float(rng.uniform(20, 220)))) == 1
+            flt.synchronize()
+            t3 = time.perf_counter()
+            for name, (ms, cnt) in flt.profile().items():
+                a = kern.setdefault(name, [0.0, 0])
+                a[0] += ms
+                a[1] += cnt
+            flt.set_option(2, 0)
+            sid = np.concatenate([np.delete(sid, drop), -np.ones(len(drop), np.int64)])
+            t_rm.append((t2 - t1, n_state))
+            t_add.append(t3 - t2)
+            n_rm.append(len(drop))
+        else:
+            t_steps += 0.0
+    flt.synchronize()
+    if not t_rm:
+        flt.close()
+        return {"note": f"--resize-every {every}: no event inside {frames} frames"}
+    n_state = int(np.median([ns for _, ns in t_rm]))
+    cms, ccnt = kern.get("compact_transform", (0.0, 0))
+    ams, acnt = kern.get("add_feature", (0.0, 0))
+    out = {"every_frames": every, "events": len(t_rm), "features_removed_and_added_per_event": int(np.median(n_rm)),
+           "state_dim": n_state,
+           "remove_ms_per_event": round(1e3 * float(np.median([t for t, _ in t_rm])), 3),
+           "add_ms_per_event": round(1e3 * float(np.median(t_add)), 3),
+           "add_ms_per_feature": round(1e3 * float(np.median(t_add)) / max(1, int(np.median(n_rm))), 4),
+           "basis": "wall time between synchronisations, per event (a removal call of 1 % of the features, then one "
+                    "ekf_add_feature per new feature); kernels from EKF_OPT_PROFILE = 2 events during the events only"}
+    if ccnt:
+        t_k = cms / ccnt * 1e-3
+        nbytes = 2.0 * n_state * n_state * 4
+        out["compact_transform"] = {"kernel": "k_compact_transform (vR.cpp:373-421, 741-772)", "bound": "hbm", "launches": ccnt,
+                                    "avg_launch_ms": round(t_k * 1e3, 4), "algorithmic_bytes_per_launch": nbytes,
+                                    "achieved": round(nbytes / t_k / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                    "frac": round(nbytes / t_k / 1e9 / PEAK_HBM_GBS, 4)}
+    if acnt:
+        out["add_feature_kernels"] = {"kernels": "k_add_prepare + k_add_border (vR.cpp:309-371)", "launches": acnt,
+                                      "avg_launch_ms": round(ams / acnt, 4)}
+    flt.close()
+    return out
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks as fresh child processes through
     torch.distributed.run, exactly as the driver does, forward rank 0's JSON line and exit with the child's
@@ -343,7 +424,7 @@ def main():
 
 def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
     frames = args.warmup + args.steps
-    opts = [(3, args.pipeline)] + ([(4, 1)] if args.split_bf16 else [])
+    opts = [(3, args.pipeline)] + ([(4, 0)] if args.exact_fp32 else [])
     flt = FilterRing(pkg, cfg, n_feat, px0, z, frames, opts)
     n = flt.filters[0].stateDim()
     d_z = torch.from_numpy(z.reshape(z.shape[0], -1)).to(dev).contiguous()
@@ -381,24 +462,40 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
     syrk_ms, syrk_cnt = prof.get("downdate_syrk", (0.0, 0))
     roofline = None
     pieces = 1
+    # which arithmetic the downdate ran in: the library switches to the bf16x6 kernel for maps of >= 23 tile rows
+    split_used = (not args.exact_fp32) and (-(-n // 128)) * ((-(-n // 128)) + 1) // 2 >= 256
     if syrk_cnt:
         # the timed launches and their algorithmic flop come from the library (ekf_profile_read / ekf_profile_work):
-        # n^2 x the real columns of every downdate launch (symmetric half); with the default pipeline the
-        # first chunk's launch also carries that chunk's W update (2 (n+1)(m - c1) x its columns), counted with it.
+        # n^2 x the real columns of every downdate launch (symmetric half).  Exact-fp32 path with the default
+        # pipeline: the first launches also carry the right-looking update of the innovation ROW of their chunk
+        # (2 x 1 x (m - c1) x its columns; the whole W, 2 (n + 1) (m - c1) x its columns, under EKF_OPT_W_RECOMPUTE = 0).
         t_k = syrk_ms / syrk_cnt * 1e-3
         # launches per step: the timed launches / the steps that were timed (every `sample`-th of the K steps)
         pieces = max(1, round(syrk_cnt / max(1, -(-args.steps // sample))))
         flop = work.get("downdate_syrk", 0.0) / syrk_cnt
         ach = flop / t_k / 1e12
-        roofline = {"kernel": "downdate_syrk (k_gemm_nt_mfma, f32 MFMA 32x32x2)", "bound": "mfma",
-                    "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_MFMA_TF, 4), "traffic": None,
-                    "avg_launch_ms": round(t_k * 1e3, 4), "launches": syrk_cnt, "timed_every_nth_step": sample,
-                    "algorithmic_flop_per_launch": flop, "launches_per_step": pieces,
-                    "note": ("%d launches per step (column chunks of V; all but the last on 224 of 256 CUs beside the "
-                             "serial Cholesky chain, EKF_OPT_PIPELINE; the first also carries its chunk's W update); "
-                             "--pipeline 0 runs one launch" % pieces)
-                            if pieces > 1 or args.pipeline != 0 else "one launch per step"}
+        note = ("%d launches per step (column chunks of V; all but the last on 224 of 256 CUs beside the serial Cholesky "
+                "chain, EKF_OPT_PIPELINE); --pipeline 0 runs one launch" % pieces) if pieces > 1 or args.pipeline != 0 \
+            else "one launch per step"
+        if split_used:
+            # the kernel executes SIX bf16 products per algorithmic fp32 product: its MFMA roofline is the dense bf16 peak
+            # over 6.  `achieved` stays the ALGORITHMIC fp32 flop over the measured duration.
+            peak6 = PEAK_BF16_MFMA_TF / 6.0
+            roofline = {"kernel": "downdate_syrk (k_syrk_bf16x6: v_mfma_f32_32x32x16_bf16 on 3 x bf16 split operands, six "
+                                  "products per fp32 product, fp32 accumulate; operands by LDS-DMA from the plane image of V_g)",
+                        "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak6, 1),
+                        "unit": "TFLOP/s (algorithmic fp32 flop)", "frac": round(ach / peak6, 4), "traffic": None,
+                        "peak_basis": "dense bf16 MFMA peak %.0f TFLOP/s / 6 products per fp32 product" % PEAK_BF16_MFMA_TF,
+                        "executed_bf16_tflops": round(6.0 * ach, 1),
+                        "vs_f32_mfma_peak": round(ach / PEAK_F32_MFMA_TF, 4),
+                        "avg_launch_ms": round(t_k * 1e3, 4), "launches": syrk_cnt, "timed_every_nth_step": sample,
+                        "algorithmic_flop_per_launch": flop, "launches_per_step": pieces, "note": note}
+        else:
+            roofline = {"kernel": "downdate_syrk (k_gemm_mfma<DOWNDATE>, f32 MFMA 32x32x2)", "bound": "mfma",
+                        "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_F32_MFMA_TF, 4), "traffic": None,
+                        "avg_launch_ms": round(t_k * 1e3, 4), "launches": syrk_cnt, "timed_every_nth_step": sample,
+                        "algorithmic_flop_per_launch": flop, "launches_per_step": pieces, "note": note}
 
     # the whole step against the f32 MFMA peak: algorithmic flop of the formulation THIS run executed, from the library's
     # own column chunks (ekf_get_chunk_plan): symmetric-half downdate n^2 m; V_g = W_g Z_gg per chunk, n w_g^2 (Z_gg upper
@@ -421,6 +518,12 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
                      "flop_breakdown": {"downdate": float(n) * n * m, "solve": solve_flop, "w_update": wupd_flop,
                                         "w_reevaluation": reval_flop, "cholesky_and_chunk_inverses": chol_flop},
                      "chunk_ends_block_steps": ends, "block": block, "w_recompute": wrec,
+                     "flop_of_the_round_1_3_formulation": float(n) * n * m + float(n) * m * m / 2.0 * 1.1 + chol_flop
+                     + sum(2.0 * n * w * max(0, m - c1) for w, c1 in zip(widths, c1s)) + 26.0 * n * m + 26.0 * m * m,
+                     "flop_note": "a LOWER whole-step fraction than in rounds 1-3 (0.50) with a higher updates/s is fewer flop per "
+                                  "step (the W update of 15 GFLOP is gone since round 4), not a slower chip; under the default "
+                                  "EKF_OPT_SPLIT_BF16 = 1 the downdate's flop run on the bf16 pipe, so this fraction of the F32 "
+                                  "peak is a lower bound on nothing -- it is kept for continuity with rounds 1-4",
                      "basis": "whole step: algorithmic flop of the formulation executed (the library's column chunks) / "
                               "ms_per_step, against the f32 MFMA peak"}
 
@@ -433,21 +536,28 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
         pmc, pmc_note = LIVE_PMC
     elif LIVE_PMC[1]:
         pmc_note = LIVE_PMC[1]
-    for tag in (() if pmc else ("r3", "r2", "r1")):
-        pmc_path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
-        if n_feat == 1000 and os.path.exists(pmc_path):
+    if not pmc and n_feat == 1000:
+        # the newest committed pass whose csrc fingerprint matches the sources of this run (profiles/r<k>_pmc_traffic.json)
+        import glob
+        import re
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")),
+                       key=lambda f: -int(re.search(r"r(\d+)_pmc", os.path.basename(f)).group(1)))
+        seen = []
+        for pmc_path in files:
             doc = json.load(open(pmc_path))
+            seen.append(f"{os.path.basename(pmc_path)}:{doc.get('csrc_sha16')}")
             if doc.get("csrc_sha16") == csrc_sha():
                 pmc = doc["kernels"]
-                pmc_note = (f"profiles/{tag}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                pmc_note = (f"profiles/{os.path.basename(pmc_path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                             f"FETCH_SIZE x2), collected on these kernel sources (csrc sha {doc['csrc_sha16']})")
                 if LIVE_PMC[1]:
                     pmc_note = f"live pass unavailable ({LIVE_PMC[1]}); " + pmc_note
-            else:
-                pmc_note = (f"profiles/{tag}_pmc_traffic.json predates the kernel sources of this run "
-                            f"(csrc sha {doc.get('csrc_sha16')} != {csrc_sha()}): traffic not reported")
-            break
-    dd_key = next((k for k in pmc if k.startswith("k_gemm_mfma<2, false")), None)     # ROLE 2 = downdate
+                break
+        else:
+            pmc_note = ((f"live pass unavailable ({LIVE_PMC[1]}); " if LIVE_PMC[1] else "") +
+                        f"no committed PMC pass matches the kernel sources of this run (csrc sha {csrc_sha()}; have "
+                        f"{', '.join(seen) or 'none'}): traffic not reported")
+    dd_key = next((k for k in pmc if k.startswith("k_syrk_bf16x6" if split_used else "k_gemm_mfma<2, false")), None)
     if roofline:
         roofline["traffic"] = pmc[dd_key]["hbm_bytes_per_launch"] if dd_key else None
         roofline["traffic_source"] = pmc_note
@@ -456,7 +566,11 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
         "value": round(args.steps / elapsed, 2), "unit": "updates/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f32 (downdate: 3 x bf16 split operands, f32 accumulate)" if args.split_bf16 else "f32",
+        "vs_baseline": None,
+        "dtype": "f32" if not split_used else
+                 "f32 (state, covariance, every accumulation and every other contraction in fp32; the products of the covariance "
+                 "downdate as 3 x bf16 splits of the fp32 operands, six bf16 products per fp32 product, exact to 2^-25 |a||b| "
+                 "-- below half an ulp of the fp32 product; EKF_OPT_SPLIT_BF16 = 0 / --exact-fp32 runs v_mfma_f32_32x32x2_f32)",
         "data": "synthetic",
         "config": {"workload": f"N={n_feat} inverse-depth features, n={n}, M=N measured per frame, "
                                f"fp32, 1xMI355X ({ {200: 'BASELINE configs[1]', 1000: 'BASELINE configs[2]', 4000: 'BASELINE configs[4] size on one GPU'}.get(n_feat, 'custom size') })",
@@ -556,11 +670,10 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
                 "kernel_ms_per_step": {kname: round(v, 4) for kname, (v, _) in sorted(per.items(), key=lambda kv: -kv[1][0])[:8]}}
             flt6.close()
 
-        if n_feat >= 600 and not args.split_bf16 and args.secondary_split_bf16:
-            # opt-in variant (NOT the headline, not the default): the covariance downdate on the bf16 matrix pipe
-            # with every fp32 operand split exactly into 3 x bf16 (EKF_OPT_SPLIT_BF16; accuracy against fp64 in
-            # tests/test_gpu_parity.py::test_split_bf16_downdate_is_fp32_accurate, tools/split_accuracy.py)
-            flt4 = FilterRing(pkg, cfg, n_feat, px0, z, frames, [(3, args.pipeline), (4, 1)])
+        if split_used and not args.no_secondary_exact_fp32:
+            # the same steps with every contraction on the f32 matrix instruction (EKF_OPT_SPLIT_BF16 = 0: the arithmetic of
+            # rounds 1-4), so that the line carries both figures
+            flt4 = FilterRing(pkg, cfg, n_feat, px0, z, frames, [(3, args.pipeline), (4, 0)])
             run_steps(flt4, d_z, d_idx, n_feat, 0, args.warmup, bpf)
             flt4.synchronize()
             t0 = time.perf_counter()
@@ -568,9 +681,10 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
             flt4.synchronize()
             t1 = time.perf_counter()
             mu4 = flt4.at(frames - 1).getFullState()
-            result["secondary_split_bf16"] = {
-                "option": "EKF_OPT_SPLIT_BF16 = 1 (off by default)", "value": round(args.steps / (t1 - t0), 2),
+            result["secondary_exact_fp32"] = {
+                "option": "EKF_OPT_SPLIT_BF16 = 0 (every contraction v_mfma_f32_32x32x2_f32)", "value": round(args.steps / (t1 - t0), 2),
                 "unit": "updates/s", "ms_per_step": round(1e3 * (t1 - t0) / args.steps, 4),
+                "max_abs_mu_difference_to_the_default_path": float(np.abs(mu4 - mu).max()),
                 "run_sane": bool(np.all(np.isfinite(mu4)) and abs(np.linalg.norm(mu4[3:7]) - 1) < 1e-4)}
             flt4.close()
 
@@ -639,6 +753,9 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
                              "fused update); 3 n^2 s = 0.5 MB of traffic per step"},
                 "run_sane": bool(np.all(np.isfinite(mu7)) and abs(np.linalg.norm(mu7[3:7]) - 1) < 1e-4)}
             flt7.close()
+
+    if args.resize_every > 0:
+        result["resize"] = resize_pass(pkg, cfg, n_feat, px0, z, args)
 
     if not args.no_cpu_baseline:
         threads = args.cpu_threads or len(os.sched_getaffinity(0))

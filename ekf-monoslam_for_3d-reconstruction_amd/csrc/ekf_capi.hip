@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -190,12 +191,13 @@ struct Filter : FilterBase {
   hipStream_t stream_g = nullptr;                       // sharded step: the all-gathers of V_g, beside the rank's solves
   hipEvent_t ev_gath[8] = {}, ev_g = nullptr;
   int solve64_off = 0, solve6464_off = 0, tri64_off = 0, tri64_count = 0;
+  int tri6_off = 0;                                      // the lower-triangular list, diagonal tiles first (k_syrk_bf16x6)
   int trih_off = 0, trih_count = 0;                      // the 128 x 128 list with its last opt_split_tail tiles as 64 x 128 halves
   // EKF_SPLIT_TAIL (-1: 1.5 tiles per CU, at most a third of the list): tiles at the end of the LAST downdate's queued list
   // that go out as 64 x 128 halves.  Measured at N = 1000: 384 halves 1.348 -> 1.329 ms (on the CU-masked side stream: no gain).
   int opt_split_tail = -1;
   double opt_feature_noise = 0.0;                       // EKF_OPT_FEATURE_NOISE: variance added to every feature state per predict
-  int opt_split_bf16 = 0;                               // EKF_OPT_SPLIT_BF16: downdate on the bf16 matrix pipe, 3 x bf16 per operand (ekf_syrk6.hpp)
+  int opt_split_bf16 = 1;                               // EKF_OPT_SPLIT_BF16 (default on, round 5): downdate of large maps on the bf16 matrix pipe, 3 x bf16 per operand, six products (ekf_syrk6.hpp)
   s6_u32x4* d_Vimg = nullptr;                           // plane image of V: (n_pad + 128) / 128 row blocks x ldy / 16 records of 12 KB
   int last_nchunks = 1, last_cend[8] = {};
   // image side (8f4): current frame, templates (original / matching), blur-pose predictions, match results
@@ -223,6 +225,7 @@ struct Filter : FilterBase {
   int opt_solve_one_per_cu = 1;                         // EKF_SOLVE_ONE_PER_CU: the last solve on one workgroup per CU when it has 1 .. 2 tiles per CU
   bool solve_one_per_cu_now = false;
   int opt_wrecompute = 1;                               // EKF_OPT_W_RECOMPUTE / EKF_W_RECOMPUTE: next chunk's W re-evaluated from the downdated Sigma
+  int opt_row_gemv = 1;                                 // EKF_ROW_GEMV=0: the innovation-row update through the tile GEMM (A/B, bit-identity check)
   int opt_fuse_wu = 1;                                  // EKF_FUSE_WU: 0 never, 1 every overlapped chunk but the one before the last, 2 every overlapped chunk
   int env_chunks[8] = {}, env_nchunks = 0;               // EKF_CHUNKS="5,10,14,16": tuning knob (block steps)
   int opt_pipeline = -1;                                 // -1 auto: on when the chain has >= 8 block steps
@@ -256,7 +259,7 @@ struct Filter : FilterBase {
                     d_flags, d_cflag, d_Jy, d_Yxyz, d_map_src, d_map_conv, d_Y, d_W, d_V, d_Dinv, d_z, d_midx,
                     d_status, d_tmp, d_K, d_tilemap, d_counters, d_ibuf, d_rmask, d_pts, d_tab,
                     d_frame, d_patch[0], d_patch[1], d_mpatch[0], d_mpatch[1], d_hb, d_zm, d_found, d_score, d_keep,
-                    d_Vimg, d_stage_send, d_stage_recv, d_archive, d_arch_idx, d_panel_tiles, d_shard_solve};
+                    d_Vimg, d_stage_send, d_stage_recv, d_archive, d_arch_idx, d_panel_tiles, d_shard_solve, d_shard_syrk};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int s = 0; s < kInSlots; ++s) { if (h_in[s]) hipHostFree(h_in[s]); if (ev_in[s]) hipEventDestroy(ev_in[s]); }
     if (h_pred) hipHostFree(h_pred);
@@ -414,6 +417,7 @@ struct Filter : FilterBase {
         HIPCHK(hipStreamCreateWithFlags(&stream_c, hipStreamNonBlocking));
       }
       if (const char* e = getenv("EKF_FUSE_WU")) opt_fuse_wu = atoi(e);
+      if (const char* e = getenv("EKF_ROW_GEMV")) opt_row_gemv = atoi(e) ? 1 : 0;
       if (const char* e = getenv("EKF_SOLVE_ONE_PER_CU")) opt_solve_one_per_cu = atoi(e) ? 1 : 0;
       if (const char* e = getenv("EKF_W_RECOMPUTE")) opt_wrecompute = atoi(e) ? 1 : 0;   // = EKF_OPT_W_RECOMPUTE, for A/B runs
       if (const char* e = getenv("EKF_SOLVE_S2")) opt_solve_s2 = atoi(e);
@@ -1158,6 +1162,10 @@ struct Filter : FilterBase {
               if (j <= i) { tm.push_back(i); tm.push_back(j); }
       tri64_count = ((int)tm.size() - tri64_off) / 2;
     }
+    tri6_off = (int)tm.size();                     // k_syrk_bf16x6: the diagonal tiles first (their element-wise epilogue is the
+    for (int i = 0; i < nt; ++i) { tm.push_back(i); tm.push_back(i); }   // longest: not in the tail of the launch), then the rest
+    for (int t = 0; t < tri_count; ++t)
+      if (tm[2 * t] != tm[2 * t + 1]) { tm.push_back(tm[2 * t]); tm.push_back(tm[2 * t + 1]); }
     trih_off = (int)tm.size();
     {
       const int ns_ = (opt_split_tail < 0) ? std::min(3 * num_cus / 2, tri_count / 3) : std::min(opt_split_tail, tri_count);
@@ -1196,10 +1204,15 @@ struct Filter : FilterBase {
       // wider last chunk, whose downdate has every CU
       // round 4 (EKF_OPT_W_RECOMPUTE: no W update, the chain as fast as the second stream): 3 / 7 / 16 -- the last chunk's
       // downdate has every CU and the largest K (tools/knob_ab.py: 1.169 ms against 1.187 with 3 / 8 / 16, 1.216 with 3 / 6)
-      static const int kEnd16[3] = {3, 7, 16};
+      // round 5 (EKF_OPT_SPLIT_BF16, the downdate 1.5 x faster): the second stream has slack beside the chain, so a FOURTH
+      // chunk pays: 2 / 6 / 11 / 16 -- the exposed first chunk and the exposed last chunk both get shorter (tools/knob_ab.py:
+      // 1.063 ms with 3 / 7 / 16, 1.049 with 3 / 7 / 12 / 16, 1.032 with 2 / 6 / 11 / 16; five chunks 1.09-1.11)
+      const bool four = kIsF32 && opt_split_bf16 && opt_mfma && nsteps >= 12 && nsteps < 32;
+      static const int kEnd16[3] = {3, 7, 16}, kEnd16s[4] = {2, 6, 11, 16};
+      const int ng = four ? 4 : 3;
       int k = 0, prev = 0;
-      for (int g = 0; g < 3; ++g) {
-        int e = (g == 2) ? nsteps : (nsteps * kEnd16[g] + 8) / 16;
+      for (int g = 0; g < ng; ++g) {
+        int e = (g == ng - 1) ? nsteps : (nsteps * (four ? kEnd16s[g] : kEnd16[g]) + 8) / 16;
         if (nsteps >= 32 && g == 0) e = 3 + (nsteps - 16) / 16;
         if (nsteps >= 32 && g == 1) e = (int)(2.0 + 0.36 * nsteps + 0.5);
         if (e > prev) { cend[k++] = e; prev = e; }
@@ -1489,9 +1502,15 @@ struct Filter : FilterBase {
       if (c1 < m_pad && !fuse && recompute) {
         // only the innovation row (row npad_live of [W; nu^T]) is updated right-looking: nu^T[c1:] -= y_g^T L[c1:, g]^T
         Scope sc(this, KID_WUPDATE, ss);
-        gemm<ROLE_WUPDATE, false, 64, 128>(d_V + (size_t)npad_live * ldy + c0, ldy, Y + (size_t)c1 * ldy + c0, ldy,
-                                           d_W + (size_t)npad_live * ldy + c1, ldy, nb, m_pad - c1, width, T(-1), T(1), 0, 0, 0,
-                                           0, 0, ss);
+        if constexpr (kIsF32) {
+          if (opt_row_gemv)
+            k_innov_row_update<<<(m_pad - c1 + 63) / 64, 64, 0, ss>>>(d_V + (size_t)npad_live * ldy + c0, Y + (size_t)c1 * ldy + c0, ldy,
+                                                                      d_W + (size_t)npad_live * ldy + c1, m_pad - c1, width);
+        }
+        if (!kIsF32 || !opt_row_gemv)
+          gemm<ROLE_WUPDATE, false, 64, 128>(d_V + (size_t)npad_live * ldy + c0, ldy, Y + (size_t)c1 * ldy + c0, ldy,
+                                             d_W + (size_t)npad_live * ldy + c1, ldy, nb, m_pad - c1, width, T(-1), T(1), 0, 0, 0,
+                                             0, 0, ss);
       } else if (c1 < m_pad && !fuse) {
         Scope sc(this, KID_WUPDATE, ss);
         const int slots = 2 * (overlap ? num_cus - reserved_cus : num_cus);
@@ -1530,7 +1549,8 @@ struct Filter : FilterBase {
           }
           Scope sc(this, KID_DOWNDATE, ss);
           if (sc.on) prof_work[KID_DOWNDATE] += double(n) * n * (std::min(c1, m) - std::min(c0, m));
-          Syrk6Args a{d_Vimg, ldy / 16, c0 / 16, width / 16, S(), ld, d_tilemap, tri_count, d_counters + counter_next, 2, 0, 0, 0};
+          Syrk6Args a{d_Vimg, ldy / 16, c0 / 16, width / 16, S(), ld, d_tilemap + tri6_off, tri_count, d_counters + counter_next,
+                      0, 0, INT_MAX};
           counter_next += 8;
           const int wgs = 2 * (overlap ? (num_cus - reserved_cus) : num_cus);
           k_syrk_bf16x6<0><<<std::min(tri_count, wgs), 256, 0, ss>>>(a);
@@ -2219,6 +2239,39 @@ struct Filter : FilterBase {
     return EKF_OK;
   }
 
+  // Canonical tiles (bi >= bj) of the bf16x6 downdate that touch a row block with a valid row of this rank (the camera
+  // block and the blocks of the own rows [r0, r1)), diagonal tiles first, then the plain path's super-tile order.  What
+  // each tile reads and stores is decided in the kernel, row by row (k_syrk_bf16x6: cam, v_lo, v_hi).
+  int* d_shard_syrk = nullptr;
+  size_t shard_syrk_cap = 0;
+  int shard_syrk_n = 0;
+  std::vector<int> shard_syrk_key;
+  int ensure_shard_syrk_list(int r0, int r1, int npad_live) {
+    std::vector<int> key = {r0, r1, npad_live, camera_dim};
+    if (key == shard_syrk_key) return EKF_OK;
+    const int nt = npad_live / 128, SB = 8, ns = (nt + SB - 1) / SB;
+    auto touched = [&](int b) { return b * 128 < camera_dim || (r1 > r0 && b * 128 < r1 && b * 128 + 128 > r0); };
+    std::vector<int> tl;
+    for (int i = 0; i < nt; ++i) if (touched(i)) { tl.push_back(i); tl.push_back(i); }
+    for (int si = 0; si < ns; ++si)
+      for (int sj = 0; sj <= si; ++sj)
+        for (int i = si * SB; i < std::min(nt, (si + 1) * SB); ++i)
+          for (int j = sj * SB; j < std::min(nt, (sj + 1) * SB); ++j)
+            if (j < i && (touched(i) || touched(j))) { tl.push_back(i); tl.push_back(j); }
+    HIPCHK(hipStreamSynchronize(stream));
+    if (stream_b) HIPCHK(hipStreamSynchronize(stream_b));
+    if (tl.size() > shard_syrk_cap) {
+      if (d_shard_syrk) HIPCHK(hipFree(d_shard_syrk));
+      d_shard_syrk = nullptr;
+      HIPCHK(hipMalloc(&d_shard_syrk, std::max<size_t>(tl.size(), 2) * sizeof(int)));
+      shard_syrk_cap = tl.size();
+    }
+    if (!tl.empty()) HIPCHK(hipMemcpy(d_shard_syrk, tl.data(), tl.size() * sizeof(int), hipMemcpyHostToDevice));
+    shard_syrk_n = (int)tl.size() / 2;
+    shard_syrk_key = key;
+    return EKF_OK;
+  }
+
   // Heaviest-first tile list of the triangular solve on a rank's row panel (64 x 128 tiles; the same order as the plain
   // path's list: column tile ntc - 1 first, every row tile of the panel per column tile).  Round 4: the sharded solve ran
   // as a plain 2-D grid of 128 x 128 tiles, whose static placement pairs the heavy tiles of a column on the same CUs:
@@ -2699,7 +2752,32 @@ struct Filter : FilterBase {
       dim3 grid((m_pad + 255) / 256, strip_rows);
       k_set_identity_strip<T><<<grid, 256, 0, stream>>>(Zs, ldy, m_pad, tab); }
     const ShardTab rtab = row_tab();
-    auto downdate_chunk = [&](int c0, int c1, hipStream_t ss) {
+    bool shard_split = false;
+    if constexpr (kIsF32) shard_split = opt_split_bf16 && opt_mfma && nb == 128 && npad_live / 128 >= 23;   // (as the plain path: tri_count >= num_cus)
+    if (shard_split) { rc = ensure_shard_syrk_list(r0, r1, npad_live); if (rc) return rc; }
+    auto downdate_chunk = [&](int c0, int c1, hipStream_t ss) -> int {
+      if constexpr (kIsF32) {
+        if (shard_split && counter_next + 8 <= kQueueCounters) {
+          // EKF_OPT_SPLIT_BF16: V_g (every row: the gather is done) -> plane image, then ONE launch over the canonical tiles
+          // that touch the camera block or an own block; each element pair is the same sum as on the plain path
+          if (!d_Vimg) HIPCHK(hipMalloc(&d_Vimg, (size_t)(n_pad + 128) * ldy * 6));
+          {
+            Scope sc(this, KID_MISC, ss);
+            dim3 grid(npad_live / 128, (c1 - c0) / 16);
+            k_split_image<<<grid, 256, 0, ss>>>(d_V, ldy, npad_live, c0, c1 - c0, d_Vimg, ldy / 16);
+          }
+          if (shard_syrk_n > 0) {
+            Scope sc(this, KID_DOWNDATE, ss);
+            if (sc.on) prof_work[KID_DOWNDATE] += 2.0 * 128 * 128 * shard_syrk_n * double(std::min(c1, m) - std::min(c0, m));
+            Syrk6Args a{d_Vimg, ldy / 16, c0 / 16, (c1 - c0) / 16, S(), ld, d_shard_syrk, shard_syrk_n, d_counters + counter_next,
+                        camera_dim, r0, r1};
+            counter_next += 8;
+            const int wgs = 2 * ((ss == stream_b) ? (num_cus - reserved_cus) : num_cus);
+            k_syrk_bf16x6<0><<<std::min(shard_syrk_n, wgs), 256, 0, ss>>>(a);
+          }
+          return EKF_OK;
+        }
+      }
       for (int q = 0; q < 2; ++q) {                        // Sigma[rows, :] -= V_g[rows] V_g^T: camera tile, own panel
         const Rows& rr = ranges[q];
         if (rr.count == 0) continue;
@@ -2715,6 +2793,7 @@ struct Filter : FilterBase {
         gemm<ROLE_DOWNDATE, false>(d_V + (size_t)rr.r0 * ldy + c0, ldy, d_V + c0, ldy, S() + (size_t)rr.r0 * ld, ld, rr.count,
                                    npad_live, c1 - c0, T(-1), T(1), 0, 0, 0, 0, 0, ss);
       }
+      return EKF_OK;
     };
     int step = 0;
     bool side_busy = false;
@@ -2776,7 +2855,8 @@ struct Filter : FilterBase {
       }
       if (pend_g >= 0) {                                   // the downdate of the previous chunk, behind this chunk's solve
         HIPCHK(hipStreamWaitEvent(stream_b, ev_gath[pend_g], 0));
-        downdate_chunk(pend_c0, pend_c1, stream_b);
+        rc = downdate_chunk(pend_c0, pend_c1, stream_b);
+        if (rc) return rc;
         pend_g = -1;
       }
       if (overlap) {
@@ -2794,7 +2874,8 @@ struct Filter : FilterBase {
           HIPCHK(hipEventRecord(ev_b, stream_b));
           HIPCHK(hipStreamWaitEvent(stream, ev_b, 0));
         }
-        downdate_chunk(c0, c1, stream);
+        rc = downdate_chunk(c0, c1, stream);
+        if (rc) return rc;
       }
     }
     HIPCHK(hipGetLastError());

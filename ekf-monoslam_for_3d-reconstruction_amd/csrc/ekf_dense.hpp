@@ -155,7 +155,7 @@ k_sigma_ht_fast(const float* __restrict__ S, int ld, int n,
                 float* __restrict__ W, int ldy, int m_pad, int nfeat, int slot0, int slot_end,
                 const float* __restrict__ z, const float* __restrict__ h, const float* __restrict__ mu,
                 float* __restrict__ nu, int* __restrict__ counters, int* __restrict__ status, float* __restrict__ q_old) {
-  constexpr int SL = 128, SEG = 6 * SL + 4;              // floats of a row segment: 2 in front, 768, 2 behind
+  constexpr int SL = 128, SEG = 6 * SL + 4;              // floats of a row segment: fp <= 3 in front, 768, the rest behind
   typedef float f4 __attribute__((ext_vector_type(4)));
   typedef float f2 __attribute__((ext_vector_type(2)));
   __shared__ __attribute__((aligned(16))) float seg[RB * SEG];
@@ -208,7 +208,11 @@ k_sigma_ht_fast(const float* __restrict__ S, int ld, int n,
 #pragma unroll
     for (int t = 0; t < 12; ++t) hf[t] = Hf[(size_t)fj * 12 + t];
   }
-  const bool lane_ok = fi >= 0 && fs == 6 && p == p_first + 6 * s && ((p_first - 2) & 3) == 0;
+  // the staged segment starts at the 16-byte boundary below the first feature: fp floats of front pad (camera_dim 14:
+  // p = 14 + 6 s, fp = 2; the literal 13 + 6 N layout: fp = 1 or 3 -- round 4 only took fp = 2 and sent every odd layout
+  // down the scalar path)
+  const int fp = p_first & 3;
+  const bool lane_ok = fi >= 0 && fs == 6 && p == p_first + 6 * s;
   const bool fast = __syncthreads_and(lane_ok ? 1 : 0) != 0;
   if (!fast) {
     // k_sigma_ht's path for (slot k, this half of the rows)
@@ -247,7 +251,7 @@ k_sigma_ht_fast(const float* __restrict__ S, int ld, int n,
   }
   // stage: RB x (SEG / 4 = 193) float4 of the feature segments + RB x 2 float4 of the camera columns
   constexpr int Q = SEG / 4, TOT = RB * Q, PER = (TOT + 255) / 256;
-  const float* sbase = S + (p_first - 2);
+  const float* sbase = S + (p_first - fp);
   // every load unconditional (indices clamped to the last slot / the last live row: a guarded load makes the compiler
   // branch around and wait for each one), all of them in flight before the first LDS write
   f4 v[PER];
@@ -270,11 +274,17 @@ k_sigma_ht_fast(const float* __restrict__ S, int ld, int n,
   for (int r = ra; r < ra + RB / 2; ++r) {
     const int i = row0 + r;
     if (i < n) {
-      const float* sr = seg + r * SEG + 2 + 6 * s;
-      const f2 x0 = *reinterpret_cast<const f2*>(sr), x1 = *reinterpret_cast<const f2*>(sr + 2), x2 = *reinterpret_cast<const f2*>(sr + 4);
+      const float* sr = seg + r * SEG + fp + 6 * s;
+      float fv[6];
+      if ((fp & 1) == 0) {                                 // 8-byte aligned: three ds_read_b64
+        const f2 x0 = *reinterpret_cast<const f2*>(sr), x1 = *reinterpret_cast<const f2*>(sr + 2), x2 = *reinterpret_cast<const f2*>(sr + 4);
+        fv[0] = x0[0]; fv[1] = x0[1]; fv[2] = x1[0]; fv[3] = x1[1]; fv[4] = x2[0]; fv[5] = x2[1];
+      } else {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) fv[t] = sr[t];
+      }
       const f4 c0 = *reinterpret_cast<const f4*>(cam + 8 * r), c1 = *reinterpret_cast<const f4*>(cam + 8 * r + 4);
       const float cvv[7] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2]};
-      const float fv[6] = {x0[0], x0[1], x1[0], x1[1], x2[0], x2[1]};
       float a0 = 0.f, a1 = 0.f;
 #pragma unroll
       for (int t = 0; t < 7; ++t) { a0 += cvv[t] * hc[t]; a1 += cvv[t] * hc[7 + t]; }
@@ -1891,6 +1901,38 @@ k_update_oneblock_small(const float* __restrict__ W, int ldw, const float* __res
       S[(size_t)r * lds_ + 64 * i + c] = sT[c * TP + r];         // the mirror tile (0, i): row r, column 64 i + c
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// Right-looking update of the innovation row alone, nu^T[c1:] -= y_g^T L[c1:, g]^T (the sequential form of the chunked
+// update keeps W by re-evaluation; of [W; nu^T] only this row is still updated by the factor): one lane per column, a serial
+// fmaf chain over the chunk's K columns IN THE ORDER THE TILE GEMM ADDS THEM (k_gemm_mfma: within every group of eight k the
+// four v_mfma_f32_32x32x2_f32 of a fragment take k = {0, 4}, {1, 5}, {2, 6}, {3, 7}), then C' = fma(-1, acc, C) -- the
+// same bits as the 64 x 128 tile launch it replaces (26 tiles, one K loop each: 20-29 us of latency at N = 1000, against
+// ~5 us here).  L rows are walked by 16-byte loads that stay in L1 (64 rows x 128 B per workgroup).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_innov_row_update(const float* __restrict__ y, const float* __restrict__ L, int ldl,
+                                                        float* __restrict__ nu, int cols, int K) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= cols) return;
+  const float* Lr = L + (size_t)c * ldl;
+  float acc = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    f32x4 b[8], a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      b[u] = *reinterpret_cast<const f32x4*>(Lr + k0 + 4 * u);
+      a[u] = *reinterpret_cast<const f32x4*>(y + k0 + 4 * u);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc = __builtin_fmaf(a[2 * s][e], b[2 * s][e], acc);            // k = 8 s + e
+        acc = __builtin_fmaf(a[2 * s + 1][e], b[2 * s + 1][e], acc);    // k = 8 s + 4 + e
+      }
+  }
+  nu[c] = __builtin_fmaf(-1.f, acc, 1.f * nu[c]);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -65,17 +65,22 @@ __global__ void __launch_bounds__(256) k_split_image(const float* __restrict__ V
 }
 
 struct Syrk6Args {
-  const s6_u32x4* img;   // plane image of V
+  const s6_u32x4* img;   // plane image of V (every row block of the state: the B side of a tile may be any block)
   int nkc_total;         // 16-column chunks per row block of the image (ldy / 16)
   int kc0;               // first chunk of this launch (c0 / 16)
-  int nk;                // chunks of this launch (chunk width / 16), >= 2
-  float* C; int ldc;     // Sigma
-  const int* tile_map; int ntiles; int* counter;   // (bi, bj) list as for k_gemm_mfma<ROLE_DOWNDATE>: kHalfTile / kMirrorTile on bi
-  int tri;               // 2: lower tiles, strictly-lower ones mirrored; 3: every listed tile, kMirrorTile ones mirrored
-  int row_off, col_off;  // tri 3 (row panel of a rank): global row / column of C's local (0, 0)
-  int a_rb0;             // row block of the image that holds local row 0 of A (tri 3); B blocks are global
+  int nk;                // chunks of this launch (chunk width / 16): even, >= 8
+  float* C; int ldc;     // Sigma (the whole matrix: tiles are addressed by global block index)
+  const int* tile_map; int ntiles; int* counter;   // CANONICAL tiles (bi >= bj, 128 x 128 blocks), host-ordered
+  // Rows of Sigma that are VALID in this address space: [0, cam) and [v_lo, v_hi).  The plain filter: every row
+  // (cam = 0, v_lo = 0, v_hi = INT_MAX).  A rank of a sharded filter: the camera rows and its own rows.
+  int cam, v_lo, v_hi;
 };
 
+// Every element pair {r, c}, r >= c, is computed ONCE, as element (r, c) of its canonical tile (A block = the block of r,
+// B block = the block of c), from the value of Sigma(r, c) -- read at (r, c) if row r is valid here, else at (c, r) -- and
+// stored at (r, c) if row r is valid and at (c, r) if row c is valid.  So Sigma is exactly symmetric, and what a rank of a
+// sharded filter holds in its rows is bit-identical to what the plain filter computes: the list of a rank is simply every
+// canonical tile that touches one of its row blocks.
 // ABL (tools/syrk6_probe.hip only): 1 = no C traffic (the accumulators are kept live), 2 = no LDS-DMA (the ring keeps what it
 // has), 4 = every LDS-DMA reads the first record (always cache hits)
 template <int ABL = 0>
@@ -87,28 +92,32 @@ __global__ void __launch_bounds__(256, 2) k_syrk_bf16x6(Syrk6Args g) {
   const int wr = wave >> 1, wc = wave & 1, h = lane >> 5, l31 = lane & 31;
   float* const C = g.C;
   const int ldc = g.ldc;
-  const int nk = g.nk;                                         // even, >= 8 (host)
+  const int nk = g.nk;
 
-  struct Tile { int rbA, rbB, arow, half, bj, mirror, diag; };
+  // validity of the 128 rows of block b: 0 none, 1 all, 2 mixed
+  auto block_class = [&](int b) {
+    const int lo = b * 128, hi = lo + 128;
+    const int n_cam = max(0, min(hi, g.cam) - lo);
+    const int o_lo = max(g.v_lo, g.cam);                       // own rows that are not camera rows
+    const int n_own = max(0, min(hi, g.v_hi) - max(lo, o_lo));
+    const int cnt = n_cam + n_own;
+    return cnt >= 128 ? 1 : (cnt > 0 ? 2 : 0);
+  };
+  auto valid = [&](int r) { return r < g.cam || (r >= g.v_lo && r < g.v_hi); };
+  struct Tile { int bi, bj, va, vb; };
   auto decode = [&](int rbi, int rbj) {
     Tile t;
-    const bool lm = (rbi & kMirrorTile) != 0;
-    t.half = (rbi & kHalfTile) ? 1 : 0;
-    const int bi = rbi & 0xffff;
+    t.bi = rbi & 0xffff;
     t.bj = rbj & 0xffff;
-    t.arow = t.half ? bi * 64 : bi * 128;                      // first local row of the tile (A and C)
-    t.rbA = g.a_rb0 + (t.arow >> 7);
-    t.rbB = t.bj;
-    const int grow0 = g.row_off + t.arow, gcol0 = g.col_off + t.bj * 128;
-    t.mirror = ((g.tri == 2 && grow0 >= gcol0 + 128) || (g.tri == 3 && lm)) ? 1 : 0;
-    t.diag = (g.tri == 2 && (grow0 >> 7) == (gcol0 >> 7)) ? 1 : 0;
+    t.va = block_class(t.bi);
+    t.vb = block_class(t.bj);
     return t;
   };
   // chunk c of tile t -> ring stage st: 24 pieces of 1 KiB, six per wave (pieces 0-11: A record, 12-23: B record)
   auto issue = [&](const Tile& t, int c, int st) {
     if (ABL & 2) return;
-    const s6_u32x4* ra = g.img + ((ABL & 4) ? (size_t)0 : ((size_t)t.rbA * g.nkc_total + g.kc0 + c) * kS6Rec);
-    const s6_u32x4* rb = g.img + ((ABL & 4) ? (size_t)0 : ((size_t)t.rbB * g.nkc_total + g.kc0 + c) * kS6Rec);
+    const s6_u32x4* ra = g.img + ((ABL & 4) ? (size_t)0 : ((size_t)t.bi * g.nkc_total + g.kc0 + c) * kS6Rec);
+    const s6_u32x4* rb = g.img + ((ABL & 4) ? (size_t)0 : ((size_t)t.bj * g.nkc_total + g.kc0 + c) * kS6Rec);
 #pragma unroll
     for (int u = 0; u < 6; ++u) {
       const int pc = wave + 4 * u;                             // u < 3: A pieces, u >= 3: B pieces
@@ -118,6 +127,7 @@ __global__ void __launch_bounds__(256, 2) k_syrk_bf16x6(Syrk6Args g) {
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
   };
+
   // ---- first tile -----------------------------------------------------------------------------------------------------
   if (tid == 0) {
     const int t = atomicAdd(g.counter, 1);
@@ -131,7 +141,8 @@ __global__ void __launch_bounds__(256, 2) k_syrk_bf16x6(Syrk6Args g) {
   int st = 0;                                                  // ring stage of the current chunk
   issue(cur, 0, 0);
   issue(cur, 1, 1);
-  bool have = true, post_epi = false;
+  bool have = true;
+  int epi_stores = -1;                                         // stores per lane the previous tile's epilogue is KNOWN to have issued (-1: no previous tile)
 
   while (have) {
     const Tile t = cur;
@@ -150,14 +161,13 @@ __global__ void __launch_bounds__(256, 2) k_syrk_bf16x6(Syrk6Args g) {
     // order it) and requests the next tile's first two chunks in the last two steps.
     const int claim_at = nk > 14 ? nk - 14 : 0;
     const int pub_at = min(claim_at + 5, nk - 5);
-    // the C tile, requested in step nk - 2 (behind that step's LDS-DMA pieces) and used in the epilogue
-    float cv[2][2][16];
-    const int rb0 = t.arow + wr * 64 + 4 * h, cb0 = t.bj * 128 + wc * 64 + l31;
     for (int s = 0; s < nk; ++s) {
-      // chunk s has landed (this wave's pieces); chunk s + 1 may be in flight -- and, in the last step, the 64 loads of the
-      // C tile behind it; behind a tile's epilogue its stores (at least 64 per lane, younger than the chunks under way)
+      // chunk s has landed (this wave's pieces); chunk s + 1 may be in flight; behind a tile's epilogue its stores, younger
+      // than the two chunks that were already under way: the wait may leave as many of them outstanding as are KNOWN to
+      // have been issued (predicated stores of diagonal / partly valid tiles are not counted: the compiler may skip them)
       const bool more1 = (s + 1 < nk) || have_next;
-      if ((s < 2 && post_epi) || s == nk - 1) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+      if (s < 2 && epi_stores >= 57) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+      else if (s < 2 && epi_stores >= 16) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
       else if (more1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                            // everybody's pieces of chunk s; everybody is out of stage st - 1
@@ -165,17 +175,6 @@ __global__ void __launch_bounds__(256, 2) k_syrk_bf16x6(Syrk6Args g) {
       const int st2 = (st == 0) ? 2 : st - 1;                  // (st + 2) % 3
       if (s + 2 < nk) issue(t, s + 2, st2);
       else if (have_next) issue(nxt, s + 2 - nk, st2);
-      if (s == nk - 2 && !(ABL & 1)) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const float* Cp = C + (size_t)(rb0 + i * 32) * ldc + cb0 + j * 32;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) cv[i][j][e] = Cp[(size_t)((e & 3) + 8 * (e >> 2)) * ldc];
-          }
-        __builtin_amdgcn_sched_barrier(0);
-      }
       // fragments of this chunk: lane = row, lane half = k half (conflict-free ds_read_b128, no swizzle)
       const s6_u32x4* Sa = lds + st * STG + h * 128 + wr * 64 + l31;
       const s6_u32x4* Sb = lds + st * STG + kS6Rec + h * 128 + wc * 64 + l31;
@@ -212,48 +211,114 @@ __global__ void __launch_bounds__(256, 2) k_syrk_bf16x6(Syrk6Args g) {
       }
       st = (st + 1 == NS) ? 0 : st + 1;
     }
-    post_epi = true;
-    // ---- epilogue: C' = C - acc (one rounding at the magnitude of C), mirror ---------------------------------------------
+    // ---- epilogue: Sigma' = Sigma - acc (one rounding at the magnitude of Sigma) -------------------------------------------
+    const bool diag = t.bi == t.bj;
+    epi_stores = (diag || (ABL & 1)) ? 0 : ((t.va == 1 ? 64 : 0) + (t.vb == 1 ? 16 : 0));
+    const int path = (ABL & 1) ? 3 : ((t.va == 1 && !diag) ? 0 : ((t.va == 0 && !diag) ? 1 : 2));
+    const int rb0 = t.bi * 128 + wr * 64 + 4 * h, cb0 = t.bj * 128 + wc * 64 + l31;
+    if (path == 0) {
+      // every row of the A block is valid here (the plain filter; the interior blocks of a rank): the whole C tile is
+      // requested at once (64 loads in flight), then direct stores, and mirror stores where the column's row is valid
+      float v[2][2][16];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if (ABL & 1) {
+        for (int j = 0; j < 2; ++j) {
+          const float* Cd = C + (size_t)(rb0 + i * 32) * ldc + cb0 + j * 32;
 #pragma unroll
-          for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc[i][j][e]));
-          continue;
+          for (int e = 0; e < 16; ++e) v[i][j][e] = Cd[(size_t)((e & 3) + 8 * (e >> 2)) * ldc];
         }
-        const int rbase = t.arow + wr * 64 + i * 32;
-        const int c = cb0 + j * 32;
-        float* Cp = C + (size_t)(rbase + 4 * h) * ldc + c;
-        float v[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = cv[i][j][e] - acc[i][j][e];
-        if (t.diag) {
-          // diagonal tile: (r, c) and (c, r) add the same six products in a different order; Sigma stays exactly symmetric
-          // by storing the lower triangle and its mirror
-          const int gr0 = g.row_off + rbase + 4 * h, gc = g.col_off + c;
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int dr = (e & 3) + 8 * (e >> 2);
-            if (gr0 + dr >= gc) {
-              Cp[(size_t)dr * ldc] = v[e];
-              C[(size_t)(gc - g.row_off) * ldc + (gr0 + dr - g.col_off)] = v[e];
-            }
-          }
-        } else {
+        for (int j = 0; j < 2; ++j) {
+          const int c = cb0 + j * 32;
+          float* Cd = C + (size_t)(rb0 + i * 32) * ldc + c;
+          float* Ct = C + (size_t)c * ldc + rb0 + i * 32;
 #pragma unroll
-          for (int e = 0; e < 16; ++e) Cp[(size_t)((e & 3) + 8 * (e >> 2)) * ldc] = v[e];
-          if (t.mirror) {
-            float* Ct = C + (size_t)(c + g.col_off - g.row_off) * ldc + (g.row_off - g.col_off);
+          for (int e = 0; e < 16; ++e) v[i][j][e] = v[i][j][e] - acc[i][j][e];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) Cd[(size_t)((e & 3) + 8 * (e >> 2)) * ldc] = v[i][j][e];
+          if (t.vb == 1 || (t.vb == 2 && valid(c))) {
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-              f32x4 o = {v[4 * gq], v[4 * gq + 1], v[4 * gq + 2], v[4 * gq + 3]};
-              *reinterpret_cast<f32x4*>(Ct + rbase + 8 * gq + 4 * h) = o;
+              f32x4 o = {v[i][j][4 * gq], v[i][j][4 * gq + 1], v[i][j][4 * gq + 2], v[i][j][4 * gq + 3]};
+              *reinterpret_cast<f32x4*>(Ct + 8 * gq) = o;
             }
           }
         }
-      }
+    } else if (path == 1) {
+      // no row of the A block is valid here: the tile only feeds the rows of its B block, read and written transposed
+      f32x4 o[2][2][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int c = cb0 + j * 32;
+          const float* Ct = C + (size_t)c * ldc + rb0 + i * 32;
+          if (t.vb == 1 || valid(c)) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) o[i][j][gq] = *reinterpret_cast<const f32x4*>(Ct + 8 * gq);
+          }
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int c = cb0 + j * 32;
+          float* Ct = C + (size_t)c * ldc + rb0 + i * 32;
+          if (t.vb == 1 || valid(c)) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+#pragma unroll
+              for (int u = 0; u < 4; ++u) o[i][j][gq][u] = o[i][j][gq][u] - acc[i][j][4 * gq + u];
+              *reinterpret_cast<f32x4*>(Ct + 8 * gq) = o[i][j][gq];
+            }
+          }
+        }
+    } else if (path == 2) {
+      // diagonal tiles ((r, c) and (c, r) add the same six products in a different order: only r >= c is used) and partly
+      // valid A blocks (the ragged ends of a rank's rows, the camera block on another rank): both images of a 32 x 32
+      // block are requested at once, then element by element
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int r0 = rb0 + i * 32, c = cb0 + j * 32;
+          float* Cd = C + (size_t)r0 * ldc + c;
+          float* Ct = C + (size_t)c * ldc + r0;
+          const bool cvalid = t.vb == 1 || (t.vb == 2 && valid(c));
+          float vd[16];
+          f32x4 ot[4];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) vd[e] = Cd[(size_t)((e & 3) + 8 * (e >> 2)) * ldc];
+          if (t.va != 1) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) ot[gq] = *reinterpret_cast<const f32x4*>(Ct + 8 * gq);
+          }
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int r = r0 + 8 * gq + u;
+              const bool rvalid = t.va == 1 || (t.va == 2 && valid(r));
+              const float cin = (t.va == 1 || rvalid) ? vd[4 * gq + u] : ot[gq][u];
+              const float x = cin - acc[i][j][4 * gq + u];
+              if (!diag || r >= c) {
+                if (rvalid) Cd[(size_t)(8 * gq + u) * ldc] = x;
+                if (cvalid && r != c) Ct[8 * gq + u] = x;
+              }
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc[i][j][e]));
+    }
     have = have_next;
     cur = nxt;
   }

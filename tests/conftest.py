@@ -11,3 +11,18 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """EKF_PARITY_CEILING_ONLY switches every measured 10 x bound of tests/helpers.bound() off (a measurement run in front
+    of tools/update_parity_bounds.py).  A test session that ran with it leaking in from the environment must not read as
+    a green parity run: unless the run also logs its measurements (EKF_PARITY_LOG: the measurement run of the
+    tool), the session FAILS."""
+    if os.environ.get("EKF_PARITY_CEILING_ONLY"):
+        msg = ("EKF_PARITY_CEILING_ONLY is set: every parity site ran against its loose hand-written ceiling only, not against "
+               "its measured bound (tests/golden/parity_bounds.json)")
+        tr = session.config.pluginmanager.get_plugin("terminalreporter")
+        if tr is not None:
+            tr.write_line("WARNING: " + msg, red=True, bold=True)
+        if not os.environ.get("EKF_PARITY_LOG") and exitstatus == 0:
+            session.exitstatus = 1

@@ -5,7 +5,8 @@
         the fp64 structured oracle (features through the batched add, predict, update over all 4000 features;
         vslamRansac.cpp:309-371, 451-603, 1245-1284) -> tests/golden/n4000_oracle_sketch.npz: mu, diag(Sigma), a few full
         rows of Sigma, Sigma R for 4 seeded Gaussian vectors R (E |D r|^2 = |D|_F^2: a sketch of the Frobenius error of the
-        whole 2.3 GB matrix in 0.8 MB) and the norms -- what tests/test_gpu_parity.py::test_n4000_matches_fp64_oracle_sketch
+        whole 2.3 GB matrix in 0.8 MB), the norms, and (round 5) the YARDSTICK: the distance of the fp32 structured oracle
+        from the fp64 one in each of those figures (o32_*: a second oracle run, ~10 GB) -- what tests/test_gpu_parity.py::test_n4000_matches_fp64_oracle_sketch
         compares the HIP filter with on the GPU box without running the oracle there.
     python tools/n4000_oracle_parity.py --hip               (GPU box)
         the same oracle run next to the HIP filter (its own 4000 fp32 adds, default options), FULL comparison of mu and of
@@ -41,20 +42,20 @@ def stream():
     return pkg, px0, z
 
 
-def run_oracle(px0, z):
+def run_oracle(px0, z, dtype=np.float64):
     import ekf_oracle as o
     import oracle_worker
     t0 = time.time()
-    ref = o.StructuredFilter(o.Config.kinect(), np.float64)
+    ref = o.StructuredFilter(o.Config.kinect(), dtype)
     ref.dT = 1.0 / 30.0
     assert ref.add_features(px0) == N
     t1 = time.time()
     for k in range(FRAMES):
         oracle_worker.predict_no_St(ref)                  # St is recomputed by the update (vR.cpp:1268)
         assert len(ref.visible_indices()) == N
-        ref.update(z[k].reshape(-1).astype(np.float64), list(range(N)))
+        ref.update(z[k].reshape(-1).astype(dtype), list(range(N)))
         ref.Kt = ref.St = None
-    print(f"oracle: adds {t1 - t0:.0f} s, {FRAMES} x (predict + update) {time.time() - t1:.0f} s", flush=True)
+    print(f"oracle ({np.dtype(dtype).name}): adds {t1 - t0:.0f} s, {FRAMES} x (predict + update) {time.time() - t1:.0f} s", flush=True)
     ref.Kt = ref.St = None
     return ref
 
@@ -99,8 +100,20 @@ def main():
         sk = sketch_of(ref.Sigma, ref.mu)
         _, fro = fro_diff(ref.Sigma, ref.Sigma)
         _, fro_f = fro_diff(ref.Sigma, ref.Sigma, r0=14)
-        np.savez_compressed(GOLDEN, fro=fro, fro_features=fro_f, sketch_seed=SKETCH_SEED, **sk)
+        # the YARDSTICK (round 5, SURVEY 8c: tolerances come from the fp32-vs-fp64 oracle gap): the same run of the fp32
+        # structured oracle, and how far IT is from the fp64 one in every figure the test compares
+        mu64, rows64, diag64, proj64 = sk["mu"], sk["rows"], sk["diag"], sk["proj"]
+        del ref
+        r32 = run_oracle(px0, z, np.float32)
+        s32 = sketch_of(r32.Sigma, r32.mu)
+        rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / np.linalg.norm(b))
+        yard = {"o32_rel_mu": rel(s32["mu"], mu64), "o32_rel_diag": rel(s32["diag"], diag64), "o32_rel_rows": rel(s32["rows"], rows64),
+                "o32_rel_row_each": np.array([rel(s32["rows"][k], rows64[k]) for k in range(len(ROWS))]),
+                "o32_rel_proj": rel(s32["proj"], proj64),
+                "o32_est_fro": float(np.linalg.norm(s32["proj"] - proj64) / np.sqrt(SKETCH_COLS) / fro)}
+        np.savez_compressed(GOLDEN, fro=fro, fro_features=fro_f, sketch_seed=SKETCH_SEED, **sk, **yard)
         print(f"wrote {GOLDEN}: {os.path.getsize(GOLDEN) / 1e6:.2f} MB, |Sigma|_F {fro:.6e}, features {fro_f:.6e}")
+        print("fp32 oracle vs fp64 oracle:", {k: (v.tolist() if hasattr(v, 'tolist') else v) for k, v in yard.items()})
         return
     if args.hip:
         f = pkg.VSlamFilter(pkg.kinect_config(), capacity_features=N)       # fp32, every option at its default

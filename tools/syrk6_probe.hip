@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <climits>
 #include <cstring>
 #include <vector>
 #include "../ekf-monoslam_for_3d-reconstruction_amd/csrc/ekf_dense.hpp"
@@ -54,7 +55,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(S, hs.data(), hs.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(S2, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
     SplitArgs a{{P[0] + c0, P[1] + c0, P[2] + c0}, ldy, S, ld, K, dplain, (int)plain.size() / 2, counters + (cn++)};
     k_syrk_bf16x3<<<512, 256>>>(a);
-    Syrk6Args b{img, nkc_total, c0 / 16, K / 16, S2, ld, dplain, (int)plain.size() / 2, counters + (cn++), 2, 0, 0, 0};
+    Syrk6Args b{img, nkc_total, c0 / 16, K / 16, S2, ld, dplain, (int)plain.size() / 2, counters + (cn++), 0, 0, INT_MAX};
     k_syrk_bf16x6<0><<<512, 256>>>(b);
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(r1.data(), S, r1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(r2.data(), S2, r2.size() * 4, hipMemcpyDeviceToHost));
@@ -72,6 +73,36 @@ int main(int argc, char** argv) {
     printf("K=%4d c0=%4d: syrk6 vs syrk3 %zu differing of %zu (changed %zu), asymmetric pairs %zu, max err vs fp64 %.3e (max |ref| %.3e)\n",
            K, c0, bad, r1.size(), changed, asym, emax, eref);
   }
+  // ---- a rank of a sharded filter: camera rows + own rows [v_lo, v_hi) valid, everything else poisoned -------------------------
+  {
+    const int K = 384, c0 = 512, cam = 14;
+    CK(hipMemcpy(S, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
+    Syrk6Args a{img, nkc_total, c0 / 16, K / 16, S, ld, dplain, (int)plain.size() / 2, counters + (cn++), 0, 0, INT_MAX};
+    k_syrk_bf16x6<0><<<512, 256>>>(a);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(r1.data(), S, r1.size() * 4, hipMemcpyDeviceToHost));
+    for (auto range : {std::pair<int, int>{cam + 6 * 300, cam + 6 * 650}, std::pair<int, int>{cam, cam + 6 * 333}, std::pair<int, int>{cam + 6 * 700, n - 130}}) {
+      const int v_lo = range.first, v_hi = range.second;
+      auto valid = [&](int r) { return r < cam || (r >= v_lo && r < v_hi); };
+      std::vector<float> hp = hs;
+      const float nanv = std::nanf("");
+      for (int r = 0; r < n; ++r) if (!valid(r)) for (int c = 0; c < n; ++c) hp[(size_t)r * ld + c] = nanv;
+      CK(hipMemcpy(S2, hp.data(), hp.size() * 4, hipMemcpyHostToDevice));
+      auto touched = [&](int b) { for (int r = b * 128; r < b * 128 + 128; ++r) if (valid(r)) return true; return false; };
+      std::vector<int> tl;
+      for (size_t t = 0; t < plain.size() / 2; ++t) if (touched(plain[2 * t]) || touched(plain[2 * t + 1])) { tl.push_back(plain[2 * t]); tl.push_back(plain[2 * t + 1]); }
+      int* dtl = up(tl);
+      Syrk6Args b{img, nkc_total, c0 / 16, K / 16, S2, ld, dtl, (int)tl.size() / 2, counters + (cn++), cam, v_lo, v_hi};
+      k_syrk_bf16x6<0><<<448, 256>>>(b);
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(r2.data(), S2, r2.size() * 4, hipMemcpyDeviceToHost));
+      size_t bad = 0, cnt = 0;
+      for (int r = 0; r < n; ++r) if (valid(r)) for (int c = 0; c < n; ++c) { ++cnt; bad += (memcmp(&r1[(size_t)r * ld + c], &r2[(size_t)r * ld + c], 4) != 0); }
+      printf("rank rows [0,%d) + [%d,%d): %zu tiles of %zu; %zu of %zu valid-row elements differ from the plain result\n", cam, v_lo, v_hi,
+             tl.size() / 2, plain.size() / 2, bad, cnt);
+      hipFree(dtl);
+    }
+  }
   // timing
   CK(hipMemset(S, 0, (size_t)n * ld * 4));
   for (int K : {384, 512, 1152}) for (int wgs : {448, 512}) for (int var = 0; var < 7; ++var) {
@@ -84,7 +115,7 @@ int main(int argc, char** argv) {
           SplitArgs a{{P[0], P[1], P[2]}, ldy, S, ld, K, dplain, (int)plain.size() / 2, counters + (cn++ % 60000)};
           k_syrk_bf16x3<<<wgs, 256>>>(a);
         } else {
-          Syrk6Args b{img, nkc_total, 0, K / 16, S, ld, dplain, (int)plain.size() / 2, counters + (cn++ % 60000), 2, 0, 0, 0};
+          Syrk6Args b{img, nkc_total, 0, K / 16, S, ld, dplain, (int)plain.size() / 2, counters + (cn++ % 60000), 0, 0, INT_MAX};
           if (var <= 2) k_syrk_bf16x6<0><<<wgs, 256>>>(b);
           else if (var == 3) k_syrk_bf16x6<1><<<wgs, 256>>>(b);
           else if (var == 4) k_syrk_bf16x6<2><<<wgs, 256>>>(b);
