@@ -2277,27 +2277,38 @@ struct Filter : FilterBase {
   // as a plain 2-D grid of 128 x 128 tiles, whose static placement pairs the heavy tiles of a column on the same CUs:
   // 0.50 ms of solves per step at N = 1000 / world 1 against 0.16 on the plain path.
   int* d_shard_solve = nullptr;
-  int shard_solve_nrt = 0;
+  int shard_solve_rows = 0;                                // row tiles per column tile of the list
+  std::vector<int> shard_solve_key;
   int shard_ntc_max() const { return ldy / 128; }
   // The list covers every column tile the workspace can hold (ldy / 128), last column tile first; a chunk of wt column tiles
-  // starts at entry (ntc_max - wt) * nrt (the entries are relative to the chunk: bj = wt - 1 .. 0), so the list depends on
-  // the number of row tiles only -- it is rebuilt (streams drained) when the panel of the rank changes its height, never
-  // because M crossed a multiple of 64
-  int ensure_shard_solve_list(int nrt) {
-    if (nrt == shard_solve_nrt) return EKF_OK;
+  // starts at entry (ntc_max - wt) * rows (the entries are relative to the chunk: bj = wt - 1 .. 0), so the list depends on
+  // the rows of the rank only -- it is rebuilt (streams drained) when the panel of the rank moves, never because M crossed a
+  // multiple of 64.  Round 5: the 64-row tiles of the camera block (when the panel does not start at row 0)
+  // and of the innovation block (rows npad_live ..) are in the SAME list, as row tiles relative to the panel's first row
+  // (negative for the camera block): one queued launch per chunk instead of three launches, two of them a single
+  // latency-bound tile row (0.31 -> 0.2 ms of solves per step at N = 1000 / world 1).
+  int ensure_shard_solve_list(int p0, int prows, int npad_live, bool with_cam) {
+    std::vector<int> key = {p0, prows, npad_live, with_cam ? 1 : 0, ldy};
+    if (key == shard_solve_key) return EKF_OK;
+    std::vector<int> rows;
+    if (with_cam) { rows.push_back(-p0 / 64); rows.push_back(-p0 / 64 + 1); }
+    for (int i = 0; i < prows / 64; ++i) rows.push_back(i);
+    rows.push_back((npad_live - p0) / 64);
+    rows.push_back((npad_live - p0) / 64 + 1);
     const int ntc = shard_ntc_max();
     std::vector<int> tl;
-    tl.reserve((size_t)2 * nrt * ntc);
+    tl.reserve((size_t)2 * rows.size() * ntc);
     for (int j = ntc - 1; j >= 0; --j)
-      for (int i = 0; i < nrt; ++i) { tl.push_back(i); tl.push_back(j); }
+      for (int bi : rows) { tl.push_back(bi); tl.push_back(j); }
     HIPCHK(hipStreamSynchronize(stream));
     if (stream_b) HIPCHK(hipStreamSynchronize(stream_b));
     if (d_shard_solve) HIPCHK(hipFree(d_shard_solve));
     d_shard_solve = nullptr;
-    shard_solve_nrt = 0;
+    shard_solve_key.clear();
     HIPCHK(hipMalloc(&d_shard_solve, tl.size() * sizeof(int)));
     HIPCHK(hipMemcpy(d_shard_solve, tl.data(), tl.size() * sizeof(int), hipMemcpyHostToDevice));
-    shard_solve_nrt = nrt;
+    shard_solve_rows = (int)rows.size();
+    shard_solve_key = key;
     return EKF_OK;
   }
 
@@ -2417,9 +2428,21 @@ struct Filter : FilterBase {
       k_sigma_ht<T, RB><<<g1, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane, d_W, ldy,
                                               m_pad, 0, camera_dim, N);
       if (r1 > r0) {
-        dim3 g2((m_pad / 2 + 255) / 256, (r1 - r0 + RB - 1) / RB);
-        k_sigma_ht<T, RB><<<g2, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane, d_W, ldy,
-                                                m_pad, r0, r1, N);
+        bool fastk = false;
+        if constexpr (kIsF32) {
+          if ((size_t)n * m_pad >= ((size_t)1 << 22)) {        // the LDS-staged kernel of the plain path on the own rows (same sums)
+            constexpr int RBf = 8;
+            dim3 g2((m_pad / 2 + 127) / 128, (r1 - r0 + RBf - 1) / RBf);
+            k_sigma_ht_fast<RBf><<<g2, 256, 0, stream>>>(S(), ld, r1, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane, d_W, ldy, m_pad, N,
+                                                         0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, r0);
+            fastk = true;
+          }
+        }
+        if (!fastk) {
+          dim3 g2((m_pad / 2 + 255) / 256, (r1 - r0 + RB - 1) / RB);
+          k_sigma_ht<T, RB><<<g2, 256, 0, stream>>>(S(), ld, n, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane, d_W, ldy,
+                                                  m_pad, r0, r1, N);
+        }
       }
     }
     {
@@ -2795,6 +2818,14 @@ struct Filter : FilterBase {
       }
       return EKF_OK;
     };
+    // Round 5: the SEQUENTIAL form of the chunked update on a rank too (EKF_OPT_W_RECOMPUTE): after the downdate of chunk g
+    // the rank re-evaluates ITS rows of W for chunk g + 1 from its downdated rows of Sigma (local: a rank holds every
+    // column of its rows), instead of the right-looking GEMM update of all later columns (0.40 of 1.56 ms per step at
+    // N = 1000 / world 1, 8.7 of 44 ms at N = 4000).  Per chunk the rank's second stream then runs solve -> gather of V_g
+    // -> downdate -> W' in series; that order is off the critical path as soon as the replicated chain is what a step
+    // waits for, which it is from two ranks on.
+    bool sh_rec = false;
+    if constexpr (kIsF32) sh_rec = opt_mfma && opt_wrecompute && nb == 128 && nchunks > 1;
     int step = 0;
     bool side_busy = false;
     int pend_c0 = -1, pend_c1 = -1, pend_g = -1;           // overlapped chunk whose downdate is still to be issued
@@ -2813,28 +2844,72 @@ struct Filter : FilterBase {
         HIPCHK(hipEventRecord(ev_b, stream_b));
         HIPCHK(hipStreamWaitEvent(stream, ev_b, 0));
       }
-      for (int q = 0; q < 3; ++q) {
+      bool solved = false;
+      if constexpr (kIsF32) {
+        if (opt_mfma && nb == 128 && prows > 0 && counter_next + 8 <= kQueueCounters) {
+          // camera block, own panel and innovation block as ONE queued launch of 64 x 128 tiles, heaviest column tiles first
+          // (row tiles relative to the panel's first row; any tile shape adds the same terms in the same order)
+          Scope sc(this, KID_SOLVE, ss);
+          solve_s2_now = want_solve_s2(width, npad_live);
+          rc = ensure_shard_solve_list(p0, prows, npad_live, ranges[0].count > 0);
+          if (rc) return rc;
+          const int wt = width / 128;
+          const size_t off = (size_t)p0 * ldy;
+          const int* list = d_shard_solve + 2 * (shard_ntc_max() - wt) * shard_solve_rows;
+          gemm<ROLE_SOLVE, true, 64, 128>(d_W + off + c0, ldy, Zs + c0, ldy, d_V + off + c0, ldy, prows, width, width, T(1),
+                                          T(0), 0, 0, 0, 1, 0, ss, list, wt * shard_solve_rows);
+          solved = true;
+        }
+      }
+      for (int q = 0; q < 3 && !solved; ++q) {
         const Rows& rr = ranges[q];
         if (rr.count == 0) continue;
         const size_t off = (size_t)rr.r0 * ldy;
         Scope sc(this, KID_SOLVE, ss);
         solve_s2_now = want_solve_s2(width, npad_live);
-        bool queued = false;
+        gemm<ROLE_SOLVE, true>(d_W + off + c0, ldy, Zs + c0, ldy, d_V + off + c0, ldy, rr.count, width, width, T(1), T(0),
+                               0, 0, 0, 1, 0, ss);
+      }
+      if (sh_rec) {
         if constexpr (kIsF32) {
-          if (q == 1 && opt_mfma && nb == 128 && counter_next + 8 <= kQueueCounters) {
-            // the own panel: 64 x 128 tiles drawn heaviest-first from a work queue (what the plain path does)
-            const int nrt = rr.count / 64, wt = width / 128;
-            rc = ensure_shard_solve_list(nrt);
+          // solve -> gather -> innovation row -> downdate -> W' of the next chunk, in this order on the chunk's stream
+          if (overlap) {
+            HIPCHK(hipEventRecord(ev_solve[gi], stream_b));
+            HIPCHK(hipStreamWaitEvent(stream_g, ev_solve[gi], 0));
+            rc = exchange_rows(d_V, ldy, rtab, c0, width, stream_g, KID_GATHER_V);
             if (rc) return rc;
-            const int* list = d_shard_solve + 2 * (shard_ntc_max() - wt) * nrt;
-            gemm<ROLE_SOLVE, true, 64, 128>(d_W + off + c0, ldy, Zs + c0, ldy, d_V + off + c0, ldy, rr.count, width, width, T(1),
-                                            T(0), 0, 0, 0, 1, 0, ss, list, wt * nrt);
-            queued = true;
+            HIPCHK(hipEventRecord(ev_gath[gi], stream_g));
+            HIPCHK(hipStreamWaitEvent(stream_b, ev_gath[gi], 0));
+          } else {
+            if (side_busy) {
+              HIPCHK(hipEventRecord(ev_g, stream_g));
+              HIPCHK(hipStreamWaitEvent(stream, ev_g, 0));
+            }
+            rc = exchange_rows(d_V, ldy, rtab, c0, width, stream, KID_GATHER_V);
+            if (rc) return rc;
           }
+          if (c1 < m_pad) {
+            Scope sc(this, KID_WUPDATE, ss);                 // nu^T[c1:] -= y_g^T L[c1:, g]^T (replicated, every rank)
+            k_innov_row_update<<<(m_pad - c1 + 63) / 64, 64, 0, ss>>>(d_V + (size_t)npad_live * ldy + c0, Y + (size_t)c1 * ldy + c0, ldy,
+                                                                      d_W + (size_t)npad_live * ldy + c1, m_pad - c1, width);
+          }
+          rc = downdate_chunk(c0, c1, ss);
+          if (rc) return rc;
+          if (gi + 1 < nchunks) {
+            Scope sc(this, KID_SIGMA_HT, ss);                // W'[rows, c1:c2) = Sigma'[rows, :] H^T, rows = camera + own
+            const int s0 = c1 / 2, s1 = cend[gi + 1] * nb / 2;
+            constexpr int RB = 8;
+            dim3 g1((s1 - s0 + 127) / 128, (camera_dim + RB - 1) / RB);
+            k_sigma_ht_fast<RB><<<g1, 256, 0, ss>>>(S(), ld, camera_dim, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane, d_W, ldy, m_pad, N,
+                                                    s0, s1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+            if (r1 > r0) {
+              dim3 g2((s1 - s0 + 127) / 128, (r1 - r0 + RB - 1) / RB);
+              k_sigma_ht_fast<RB><<<g2, 256, 0, ss>>>(S(), ld, r1, d_Hc, d_Hf, d_pos, d_coding, d_midx, M, plane, d_W, ldy, m_pad, N,
+                                                      s0, s1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, r0);
+            }
+          }
+          continue;
         }
-        if (!queued)
-          gemm<ROLE_SOLVE, true>(d_W + off + c0, ldy, Zs + c0, ldy, d_V + off + c0, ldy, rr.count, width, width, T(1), T(0),
-                                 0, 0, 0, 1, 0, ss);
       }
       if (overlap) {
         // own rows of V_g are final: their gather starts now, on the gather stream ...
@@ -2880,7 +2955,7 @@ struct Filter : FilterBase {
     }
     HIPCHK(hipGetLastError());
     last_nchunks = nchunks;
-    last_recompute = false;
+    last_recompute = sh_rec;
     for (int g = 0; g < nchunks; ++g) last_cend[g] = cend[g];
     {
       Scope sc(this, KID_STATE_UPDATE);                    // mu is replicated: every rank adds V y over all rows

@@ -154,7 +154,8 @@ k_sigma_ht_fast(const float* __restrict__ S, int ld, int n,
                 const int* __restrict__ midx, int M, int plane,
                 float* __restrict__ W, int ldy, int m_pad, int nfeat, int slot0, int slot_end,
                 const float* __restrict__ z, const float* __restrict__ h, const float* __restrict__ mu,
-                float* __restrict__ nu, int* __restrict__ counters, int* __restrict__ status, float* __restrict__ q_old) {
+                float* __restrict__ nu, int* __restrict__ counters, int* __restrict__ status, float* __restrict__ q_old,
+                int row_lo = 0) {     // rows [row_lo, n) of W (a rank of a sharded filter: its camera rows, its own rows)
   constexpr int SL = 128, SEG = 6 * SL + 4;              // floats of a row segment: fp <= 3 in front, 768, the rest behind
   typedef float f4 __attribute__((ext_vector_type(4)));
   typedef float f2 __attribute__((ext_vector_type(2)));
@@ -188,7 +189,7 @@ k_sigma_ht_fast(const float* __restrict__ S, int ld, int n,
   const int kbase = slot0 + blockIdx.x * SL;
   const int k = kbase + s;
   const int nslots = slot_end > 0 ? slot_end : m_pad / 2;
-  const int row0 = blockIdx.y * RB, row1 = min(row0 + RB, n);
+  const int row0 = row_lo + blockIdx.y * RB, row1 = min(row0 + RB, n);
   // is this workgroup's stretch of the list a run of inverse-depth features that are neighbours in the state?
   int fi = -1, p = 0, fs = 6;
   if (k < M && k < nslots) {

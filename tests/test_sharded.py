@@ -737,9 +737,9 @@ def test_hip_shard_n4000_resize_cadence_two_ranks_match_plain_path():
     # different chunk plans the two fp32 runs drift apart by 1e-5 .. 1e-3 over 100 frames -- rounding differences of
     # 1e-7 in V amplified by the filter, tools/shard_cadence_probe.py -- which would say nothing about the sharding.)
     flt.set_option(3, 4)
-    # ... and the right-looking W update of the sharded step (EKF_OPT_W_RECOMPUTE = 0; the plain path's default since
-    # round 4 re-evaluates the next chunk's W from the downdated Sigma: equal up to fp32 rounding, not to the bit)
-    flt.set_option(7, 0)
+    # (round 5: both paths run their defaults otherwise -- the covariance downdate on the bf16 matrix pipe, where every
+    # element pair of Sigma is ONE sum whichever rank computes it (k_syrk_bf16x6), and the sequential form of the chunked
+    # update, W of the next chunk re-evaluated from the downdated rows, on the ranks as on the plain path)
     for _ in n4000_cadence_run(pkg, flt, progress=lambda k: print(f"[n4000 plain] frame {k + 1}", flush=True)):
         pass
     mu_p = flt.getFullState()
