@@ -212,17 +212,32 @@ def bench(pkg, cfg, n_feat, px0, z, args, rank, world, dev):
     if dd_cnt:
         flop = work.get("downdate_syrk", 0.0) / dd_cnt
         ach = flop / (dd_ms / dd_cnt * 1e-3) / 1e12
-        roofline = {"kernel": "downdate row panel (k_gemm_mfma, f32 MFMA 32x32x2), rank 0", "bound": "mfma",
-                    "achieved": round(ach, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4),
-                    "traffic": None, "avg_launch_ms": round(dd_ms / dd_cnt, 4),
-                    "algorithmic_flop_per_launch": flop, "launches_per_step": dd_cnt / k}
+        split = n >= 23 * 128 - 127 and not os.environ.get("EKF_SPLIT_BF16") == "0"      # the library's own rule (23 tile rows)
+        if split:
+            # k_syrk_bf16x6: six bf16 products per algorithmic fp32 product -> roofline = dense bf16 peak / 6 (bench.py)
+            peak6 = 2500.0 / 6.0
+            roofline = {"kernel": "downdate of the rank's canonical tiles (k_syrk_bf16x6: v_mfma_f32_32x32x16_bf16, 3 x bf16 split "
+                                  "operands, six products per fp32 product), rank 0", "bound": "mfma",
+                        "achieved": round(ach, 2), "peak": round(peak6, 1), "unit": "TFLOP/s (algorithmic fp32 flop)",
+                        "frac": round(ach / peak6, 4), "vs_f32_mfma_peak": round(ach / 157.3, 4),
+                        "traffic": None, "avg_launch_ms": round(dd_ms / dd_cnt, 4),
+                        "algorithmic_flop_per_launch": flop, "launches_per_step": dd_cnt / k}
+        else:
+            roofline = {"kernel": "downdate row panel (k_gemm_mfma, f32 MFMA 32x32x2), rank 0", "bound": "mfma",
+                        "achieved": round(ach, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4),
+                        "traffic": None, "avg_launch_ms": round(dd_ms / dd_cnt, 4),
+                        "algorithmic_flop_per_launch": flop, "launches_per_step": dd_cnt / k}
     info = shard_info(flt)
     result = {
         "metric": "EKF updates/sec at N features (state dim 14+6N)",
         "value": round(args.steps / elapsed, 2), "unit": "updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None,
+        "dtype": "f32" if roofline is None or "bf16x6" not in roofline["kernel"] else
+                 "f32 (covariance downdate products as 3 x bf16 splits of the fp32 operands, six products per fp32 product, "
+                 "fp32 accumulate; EKF_SPLIT_BF16=0: v_mfma_f32_32x32x2_f32)",
+        "data": "synthetic",
         "config": {"workload": f"N={n_feat} inverse-depth features, n={n}, M=N measured per frame, fp32, "
                                f"row-panel shard over {world} GPUs (BASELINE configs[3])",
                    "features": n_feat, "state_dim": n, "measured_per_frame": n_feat,
