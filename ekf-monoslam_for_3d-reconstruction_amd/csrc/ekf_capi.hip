@@ -852,7 +852,7 @@ struct Filter : FilterBase {
     const int dst = 1 - cur, dmu = 1 - cur_mu;
     {
       Scope sc(this, KID_COMPACT);
-      dim3 grid((n_new + 255) / 256, n_new);
+      dim3 grid(std::min((n_new + 1023) / 1024, 8), n_new);    // four columns per lane (k_compact_transform)
       k_compact_transform<T><<<grid, 256, 0, stream>>>(S(), d_S[dst], ld, n_new, d_map_src, d_map_conv, d_Jy);
       k_compact_mu<T><<<(n_new + 255) / 256, 256, 0, stream>>>(mu(), d_mu[dmu], n_new, d_map_src, d_map_conv,
                                                               d_Yxyz);
@@ -1204,15 +1204,28 @@ struct Filter : FilterBase {
       // wider last chunk, whose downdate has every CU
       // round 4 (EKF_OPT_W_RECOMPUTE: no W update, the chain as fast as the second stream): 3 / 7 / 16 -- the last chunk's
       // downdate has every CU and the largest K (tools/knob_ab.py: 1.169 ms against 1.187 with 3 / 8 / 16, 1.216 with 3 / 6)
-      // round 5 (EKF_OPT_SPLIT_BF16, the downdate 1.5 x faster): the second stream has slack beside the chain, so a FOURTH
-      // chunk pays: 2 / 6 / 11 / 16 -- the exposed first chunk and the exposed last chunk both get shorter (tools/knob_ab.py:
-      // 1.063 ms with 3 / 7 / 16, 1.049 with 3 / 7 / 12 / 16, 1.032 with 2 / 6 / 11 / 16; five chunks 1.09-1.11)
-      const bool four = kIsF32 && opt_split_bf16 && opt_mfma && nsteps >= 12 && nsteps < 32;
-      static const int kEnd16[3] = {3, 7, 16}, kEnd16s[4] = {2, 6, 11, 16};
-      const int ng = four ? 4 : 3;
+      // round 5 (EKF_OPT_SPLIT_BF16, the downdate 1.5 x faster): the second stream has slack beside the chain, so one more
+      // chunk pays -- the exposed first chunk and the exposed last chunk both get shorter (tools/knob_ab.py, ms per step):
+      //   16 steps (N = 1000): 1.063 with 3 / 7 / 16, 1.049 with 3 / 7 / 12 / 16, 1.032 with 2 / 6 / 11 / 16; five chunks 1.09-1.11
+      //   32 steps (N = 2000): 5.28 with 4 / 13 / 32, 5.05 with 4 / 12 / 22 / 32, 5.09 with five chunks
+      //   63 steps (N = 4000): 35.96 with 5 / 25 / 63, 34.97 with 4 / 16 / 36 / 63, 34.27 with 4 / 14 / 30 / 46 / 63
+      const bool split = kIsF32 && opt_split_bf16 && opt_mfma;
+      if (split && nsteps >= 12) {
+        static const double f4[4] = {2.0 / 16, 6.0 / 16, 11.0 / 16, 1.0}, f4l[4] = {4.0 / 32, 12.0 / 32, 22.0 / 32, 1.0},
+                            f5[5] = {4.0 / 63, 14.0 / 63, 30.0 / 63, 46.0 / 63, 1.0};
+        const int ng = nsteps >= 48 ? 5 : 4;
+        const double* fr = nsteps >= 48 ? f5 : (nsteps >= 32 ? f4l : f4);
+        int k = 0, prev = 0;
+        for (int g = 0; g < ng; ++g) {
+          int e = (g == ng - 1) ? nsteps : (int)(fr[g] * nsteps + 0.5);
+          if (e > prev) { cend[k++] = e; prev = e; }
+        }
+        return k;
+      }
+      static const int kEnd16[3] = {3, 7, 16};
       int k = 0, prev = 0;
-      for (int g = 0; g < ng; ++g) {
-        int e = (g == ng - 1) ? nsteps : (nsteps * (four ? kEnd16s[g] : kEnd16[g]) + 8) / 16;
+      for (int g = 0; g < 3; ++g) {
+        int e = (g == 2) ? nsteps : (nsteps * kEnd16[g] + 8) / 16;
         if (nsteps >= 32 && g == 0) e = 3 + (nsteps - 16) / 16;
         if (nsteps >= 32 && g == 1) e = (int)(2.0 + 0.36 * nsteps + 0.5);
         if (e > prev) { cend[k++] = e; prev = e; }
@@ -1499,7 +1512,13 @@ struct Filter : FilterBase {
       if constexpr (kIsF32)
         fuse = opt_fuse_wu && (opt_fuse_wu > 1 || recompute || gi + 2 < nchunks) && opt_mfma && overlap && c1 < m_pad &&
                !opt_split_bf16 && tile == 128 && tri_count >= num_cus && counter_next + 8 <= kQueueCounters;
-      if (c1 < m_pad && !fuse && recompute) {
+      bool split_now = false;
+      if constexpr (kIsF32)
+        split_now = opt_split_bf16 && opt_mfma && tile == 128 && tri_count >= num_cus && counter_next + 8 <= kQueueCounters;
+      const bool row_rider = split_now && recompute && opt_row_gemv && c1 < m_pad && !fuse;   // rides in the k_split_image launch below
+      if (row_rider) {
+        // (nothing here: the row goes with the plane image)
+      } else if (c1 < m_pad && !fuse && recompute) {
         // only the innovation row (row npad_live of [W; nu^T]) is updated right-looking: nu^T[c1:] -= y_g^T L[c1:, g]^T
         Scope sc(this, KID_WUPDATE, ss);
         if constexpr (kIsF32) {
@@ -1544,8 +1563,14 @@ struct Filter : FilterBase {
           if (!d_Vimg) HIPCHK(hipMalloc(&d_Vimg, (size_t)(n_pad + 128) * ldy * 6));
           {
             Scope sc(this, KID_MISC, ss);
-            dim3 grid(npad_live / 128, width / 16);
-            k_split_image<<<grid, 256, 0, ss>>>(d_V, ldy, npad_live, c0, width, d_Vimg, ldy / 16);
+            const int gy = width / 16;
+            const int xr = row_rider ? ((m_pad - c1 + 255) / 256 + gy - 1) / gy : 0;      // extra x blocks of the rider
+            dim3 grid(npad_live / 128 + xr, gy);
+            if (row_rider)
+              k_split_image<<<grid, 256, 0, ss>>>(d_V, ldy, npad_live, c0, width, d_Vimg, ldy / 16, d_V + (size_t)npad_live * ldy + c0,
+                                                  Y + (size_t)c1 * ldy + c0, ldy, d_W + (size_t)npad_live * ldy + c1, m_pad - c1);
+            else
+              k_split_image<<<grid, 256, 0, ss>>>(d_V, ldy, npad_live, c0, width, d_Vimg, ldy / 16);
           }
           Scope sc(this, KID_DOWNDATE, ss);
           if (sc.on) prof_work[KID_DOWNDATE] += double(n) * n * (std::min(c1, m) - std::min(c0, m));

@@ -33,7 +33,35 @@ constexpr int kS6Rec = 768;                    // 16-byte slots of one record (1
 // Image slot index of (row r, column c, plane p): ((r / 128) * nkc_total + c / 16) * 768 + p * 256 + ((c % 16) / 8) * 128 + r % 128.
 // One thread per (row, 8 columns): 32 B read, three 16-byte slots written (consecutive lanes = consecutive rows).
 __global__ void __launch_bounds__(256) k_split_image(const float* __restrict__ V, int ld, int rows, int c0, int width,
-                                                    s6_u32x4* __restrict__ img, int nkc_total) {
+                                                    s6_u32x4* __restrict__ img, int nkc_total,
+                                                    // optional rider (blocks blockIdx.x >= rows / 128): the right-looking update of the
+                                                    // innovation row, nu^T[c1:] -= y_g^T L[c1:, g]^T -- k_innov_row_update's sums
+                                                    // (ekf_dense.hpp), one lane per column, 256 columns per (x, y) block
+                                                    const float* __restrict__ ry = nullptr, const float* __restrict__ rL = nullptr,
+                                                    int rldl = 0, float* __restrict__ rnu = nullptr, int rcols = 0) {
+  if ((int)blockIdx.x >= (rows + 127) / 128) {
+    const int c = ((blockIdx.x - (rows + 127) / 128) * gridDim.y + blockIdx.y) * 256 + threadIdx.x;
+    if (c >= rcols) return;
+    const float* Lr = rL + (size_t)c * rldl;
+    float acc = 0.f;
+    for (int k0 = 0; k0 < width; k0 += 32) {
+      f32x4 b[8], a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        b[u] = *reinterpret_cast<const f32x4*>(Lr + k0 + 4 * u);
+        a[u] = *reinterpret_cast<const f32x4*>(ry + k0 + 4 * u);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc = __builtin_fmaf(a[2 * s][e], b[2 * s][e], acc);            // k = 8 s + e       (the tile GEMM's order)
+          acc = __builtin_fmaf(a[2 * s + 1][e], b[2 * s + 1][e], acc);    // k = 8 s + 4 + e
+        }
+    }
+    rnu[c] = __builtin_fmaf(-1.f, acc, 1.f * rnu[c]);
+    return;
+  }
   const int r = blockIdx.x * 128 + (threadIdx.x & 127);
   const int o0 = blockIdx.y * 2 + (threadIdx.x >> 7);          // octet (8 columns) inside the launch
   if (r >= rows || o0 * 8 >= width) return;
