@@ -186,7 +186,7 @@ struct Filter : FilterBase {
   int opt_streaming = 0, opt_mfma = 1, opt_profile = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  hipStream_t stream_b = nullptr, stream_c = nullptr;   // solve pieces / downdate pieces, overlapped with the chain
+  hipStream_t stream_b = nullptr;                       // solve pieces / downdate pieces, overlapped with the chain
   hipEvent_t ev_chain[8] = {}, ev_solve[8] = {}, ev_b = nullptr, ev_c = nullptr, ev_wu = nullptr;
   hipStream_t stream_g = nullptr;                       // sharded step: the all-gathers of V_g, beside the rank's solves
   hipEvent_t ev_gath[8] = {}, ev_g = nullptr;
@@ -268,7 +268,6 @@ struct Filter : FilterBase {
     if (h_rb) hipHostFree(h_rb);
     if (own_stream && stream) hipStreamDestroy(stream);
     if (stream_b) hipStreamDestroy(stream_b);
-    if (stream_c) hipStreamDestroy(stream_c);
     if (stream_g) hipStreamDestroy(stream_g);
     for (auto e : ev_gath) if (e) hipEventDestroy(e);
     if (ev_g) hipEventDestroy(ev_g);
@@ -307,7 +306,6 @@ struct Filter : FilterBase {
     if (pending.empty()) return;
     hipStreamSynchronize(stream);
     hipStreamSynchronize(stream_b);
-    hipStreamSynchronize(stream_c);
     if (stream_g) hipStreamSynchronize(stream_g);
     for (auto& p : pending) {
       float ms = 0.f;
@@ -407,15 +405,7 @@ struct Filter : FilterBase {
         reserved_cus = 0;
         HIPCHK(hipStreamCreateWithFlags(&stream_b, hipStreamNonBlocking));
       }
-      // chain stream: ONLY the reserved CUs, so that a chain workgroup never lands next to tile-GEMM waves
-      std::vector<uint32_t> cmask((num_cus + 31) / 32, 0u);
-      for (int i = 0; i < reserved_cus; ++i) cmask[i / 32] |= (1u << (i % 32));
-      if (reserved_cus == 0 ||
-          hipExtStreamCreateWithCUMask(&stream_c, (uint32_t)cmask.size(), cmask.data()) != hipSuccess) {
-        (void)hipGetLastError();
-        stream_c = nullptr;
-        HIPCHK(hipStreamCreateWithFlags(&stream_c, hipStreamNonBlocking));
-      }
+
       if (const char* e = getenv("EKF_FUSE_WU")) opt_fuse_wu = atoi(e);
       if (const char* e = getenv("EKF_ROW_GEMV")) opt_row_gemv = atoi(e) ? 1 : 0;
       if (const char* e = getenv("EKF_SOLVE_ONE_PER_CU")) opt_solve_one_per_cu = atoi(e) ? 1 : 0;
@@ -1176,7 +1166,6 @@ struct Filter : FilterBase {
     }
     HIPCHK(hipStreamSynchronize(stream));
     HIPCHK(hipStreamSynchronize(stream_b));
-    HIPCHK(hipStreamSynchronize(stream_c));
     if (d_tilemap) HIPCHK(hipFree(d_tilemap));
     d_tilemap = nullptr;
     HIPCHK(hipMalloc(&d_tilemap, tm.size() * sizeof(int)));

@@ -436,7 +436,6 @@ struct GemmArgs {
   void* C2; int ldc2;
   int n2, nr2;
   int row2;                                     // first row tile of the second product (its tiles are rows row2 .. row2 + nr2 - 1)
-  int first_static;                             // k_gemm_pipe: workgroup b starts on list entry b, the queue hands out the entries behind the grid
 };
 constexpr int kSecondProduct = 0x10000;         // flag on bj for a tile of the second product
 constexpr int kHalfTile = 0x20000;              // flag on bi: 64-row half tile, bi & 0xffff in 64-row units (k_gemm_mfma, downdate)

@@ -1,10 +1,18 @@
 #!/bin/bash
-# Round-5 evidence in one call on the GPU box: tools/collect_profiles.sh   (outputs under gpurun_out/r5/, copied to profiles/)
+# Round-5 evidence on the GPU box, in stages that each fit one gpurun call (<= 20 min):
+#   tools/collect_profiles.sh A   bench lines, rocprofv3 kernel stats + timelines, PMC traffic, MFMA counters, resize cadence
+#   tools/collect_profiles.sh B   micro-benchmarks, sharded world 1 over RCCL, gloo rehearsals, knob A/B, accuracy of the knobs
+#   tools/collect_profiles.sh C   N = 4000 against the fp64 oracle (every entry)
+#   tools/collect_profiles.sh D   long all-measured runs (positivity)
+#   tools/collect_profiles.sh E   CPU baseline with the measured single-thread dense frame
+# outputs under gpurun_out/r5/ (copy the summaries into profiles/)
 set -e
 R="${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set (run under gpurun)}"
 O="$R/gpurun_out/r5"
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
+STAGE="${1:-A}"
+if [ "$STAGE" = A ]; then
 echo "bench N=1000"; python3 "$R/bench.py" > "$O/r5_bench.json" 2> "$O/bench.err"
 echo "bench N=200 x 1000 frames"; python3 "$R/bench.py" --features 200 --steps 1000 --warmup 10 --no-cpu-baseline > "$O/r5_bench_n200_1000frames.json" 2>> "$O/bench.err"
 echo "bench N=4000"; python3 "$R/bench.py" --features 4000 --steps 20 --warmup 3 --no-cpu-baseline --no-propagate-pass > "$O/r5_bench_n4000.json" 2>> "$O/bench.err"
@@ -41,6 +49,8 @@ cd "$R" && python3 tools/pmc_mfma.py gpurun_out/r5 gpurun_out/r5/r5_pmc_mfma.jso
 echo "configs[4] resize cadence on one GPU (N = 4000, an event every 10 frames so that a short run holds several)"
 python3 "$R/bench.py" --features 4000 --steps 40 --warmup 3 --no-cpu-baseline --no-propagate-pass --no-live-traffic --resize-every 10 > "$O/r5_bench_n4000_resize.json" 2>> "$O/bench.err"
 rm -rf "$O/prof" "$O/pmc" "$O/pmc_mfma" "$O/pmc_mfma2"
+fi
+if [ "$STAGE" = B ]; then
 echo "diagonal factor + column-chain microbenchmarks"
 "$R/tools/diag_bench" > "$O/r5_diag_bench.txt"
 "$R/tools/chain_latency" > "$O/r5_chain_latency.txt"
@@ -56,10 +66,17 @@ python3 "$R/tools/knob_ab.py" "" "EKF_SPLIT_BF16=0" "EKF_W_RECOMPUTE=0" "EKF_CHU
 KNOB_N=4000 KNOB_FRAMES=40 python3 "$R/tools/knob_ab.py" "" "EKF_SPLIT_BF16=0" "EKF_W_RECOMPUTE=0" "EKF_CHUNKS=4,16,36,63" "EKF_CHUNKS=4,14,30,46,63" 2>/dev/null > "$O/r5_knob_ab_n4000.txt"
 KNOB_N=2000 KNOB_FRAMES=80 python3 "$R/tools/knob_ab.py" "" "EKF_SPLIT_BF16=0" "EKF_W_RECOMPUTE=0" "EKF_CHUNKS=4,12,22,32" 2>/dev/null > "$O/r5_knob_ab_n2000.txt"
 python3 "$R/tools/acc_knobs.py" "" "EKF_SPLIT_BF16=0" "EKF_W_RECOMPUTE=0" "EKF_SPLIT_BF16=0 EKF_CHUNKS=3,7,16" 2>/dev/null > "$O/r5_accuracy_knobs_n1000.txt"
+fi
+if [ "$STAGE" = C ]; then
 echo "N = 4000 against the fp64 oracle, every entry (two frames)"
 python3 "$R/tools/n4000_oracle_parity.py" --hip 2>/dev/null | tail -2 > "$O/r5_n4000_oracle_parity.txt"
-echo "long all-measured runs on the round-4 path (positivity of the fp32 covariance)"
+fi
+if [ "$STAGE" = D ]; then
+echo "long all-measured runs on the round-5 default path (positivity of the fp32 covariance)"
 for nf in "1000 3000" "2000 2500" "4000 1200"; do set -- $nf; python3 "$R/tools/long_run.py" $1 $2 2>/dev/null | tail -2 > "$O/r5_long_run_n$1.txt" || true; done
+fi
+if [ "$STAGE" = E ]; then
 echo "CPU baseline with the measured single-thread dense frame (--cpu-full)"
 python3 "$R/bench.py" --steps 20 --warmup 5 --no-propagate-pass --no-live-traffic --cpu-full > "$O/r5_bench_cpu_full.json" 2>> "$O/bench.err"
+fi
 ls "$O"
