@@ -187,7 +187,7 @@ struct Filter : FilterBase {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipStream_t stream_b = nullptr;                       // solve pieces / downdate pieces, overlapped with the chain
-  hipEvent_t ev_chain[8] = {}, ev_solve[8] = {}, ev_b = nullptr, ev_c = nullptr, ev_wu = nullptr;
+  hipEvent_t ev_chain[8] = {}, ev_solve[8] = {}, ev_b = nullptr, ev_wu = nullptr;
   hipStream_t stream_g = nullptr;                       // sharded step: the all-gathers of V_g, beside the rank's solves
   hipEvent_t ev_gath[8] = {}, ev_g = nullptr;
   int solve64_off = 0, solve6464_off = 0, tri64_off = 0, tri64_count = 0;
@@ -275,7 +275,6 @@ struct Filter : FilterBase {
     for (auto e : ev_solve) if (e) hipEventDestroy(e);
     if (ev_b) hipEventDestroy(ev_b);
     if (ev_wu) hipEventDestroy(ev_wu);
-    if (ev_c) hipEventDestroy(ev_c);
   }
 
   // ---- profiling helpers ---------------------------------------------------------------
@@ -347,7 +346,6 @@ struct Filter : FilterBase {
     for (auto& e : ev_solve) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ev_b, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ev_wu, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&ev_c, hipEventDisableTiming));
     const size_t sig = (size_t)n_pad * ld;
     HIPCHK(hipMalloc(&d_S[0], sig * sizeof(T)));
     HIPCHK(hipMalloc(&d_S[1], sig * sizeof(T)));
@@ -1456,7 +1454,7 @@ struct Filter : FilterBase {
         if constexpr (kIsF32) {
           const int nrb = npad_live / 64, nt64 = nrb * (nrb + 1) / 2;
           // small map: downdate and normalisation congruence in the same launch, one 64 x 64 tile of Sigma per workgroup
-          allinone = nt64 <= num_cus && !opt_split_bf16 && !prof_on(KID_DOWNDATE) && !prof_on(KID_NORMALIZE);
+          allinone = nt64 <= num_cus && !prof_on(KID_DOWNDATE) && !prof_on(KID_NORMALIZE);
           if (allinone)
             k_update_oneblock_small<<<nt64 + 1, 512, 0, ss>>>(d_W, ldy, d_Dinv, d_V, ldy, npad_live, mu(), n, d_scr + SCR_QOLD,
                                                              d_scr + SCR_QN, Zs, ldy, S(), ld, nt64);
@@ -2790,7 +2788,8 @@ struct Filter : FilterBase {
       k_set_identity_strip<T><<<grid, 256, 0, stream>>>(Zs, ldy, m_pad, tab); }
     const ShardTab rtab = row_tab();
     bool shard_split = false;
-    if constexpr (kIsF32) shard_split = opt_split_bf16 && opt_mfma && nb == 128 && npad_live / 128 >= 23;   // (as the plain path: tri_count >= num_cus)
+    if constexpr (kIsF32)                                  // (the plain path's rule: the lower tiles of the WHOLE matrix fill the chip)
+      shard_split = opt_split_bf16 && opt_mfma && nb == 128 && (npad_live / 128) * (npad_live / 128 + 1) / 2 >= num_cus;
     if (shard_split) { rc = ensure_shard_syrk_list(r0, r1, npad_live); if (rc) return rc; }
     auto downdate_chunk = [&](int c0, int c1, hipStream_t ss) -> int {
       if constexpr (kIsF32) {

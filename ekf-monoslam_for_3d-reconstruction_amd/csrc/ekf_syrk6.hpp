@@ -1,12 +1,12 @@
 // Covariance downdate Sigma -= V_g V_g^T (a10, vR.cpp:1279) on the bf16 matrix pipe at fp32 accuracy (round 5).
 //
-// Arithmetic (the one of ekf_split.hpp, round 1): an fp32 value is the exact sum of three bf16 values, a = a1 + a2 + a3;
+// Arithmetic (the opt-in experiment of round 1, now the default for large maps): an fp32 value is the exact sum of three bf16 values, a = a1 + a2 + a3;
 // of the nine bf16 x bf16 products of a * b the six above 2^-25 |a||b| -- below half an ulp of the fp32 product -- are
 // accumulated in fp32 by v_mfma_f32_32x32x16_bf16, smallest first: a3 b1, a1 b3, a2 b2, a2 b1, a1 b2, a1 b1.  Six of those
 // instructions retire 16 k in 192 cycles where v_mfma_f32_32x32x2_f32 needs 512: the fp32-equivalent peak of the scheme
 // is 2.5 PF / 6 = 417 TF against 157 TF of the fp32 instruction.
 //
-// What makes it run near that rate is the data path, which is built around the LDS-DMA (global_load_lds_dwordx4):
+// What makes it run is the data path, which is built around the LDS-DMA (global_load_lds_dwordx4):
 //   * V_g is kept a second time as a PLANE IMAGE (k_split_image): per 128-row block and 16-column chunk one contiguous
 //     12 KB record [plane 3][k half 2][row 128][8 bf16] -- exactly the LDS image one operand of one K step needs, so a
 //     stage is filled by 1 KiB wave-instructions that are contiguous on both sides (no staging registers, no ds_write,
@@ -14,10 +14,15 @@
 //   * a ring of three 24 KB stages (A record + B record): the loads of chunk s + 2 are issued right behind the barrier of
 //     step s and stay in flight across the next barrier (raw s_barrier + counted s_waitcnt vmcnt, never __syncthreads);
 //   * fragments by ds_read_b128 straight out of the record (lane = row, lane half = k half: conflict-free, no swizzle);
-//   * persistent grid on the same host-ordered tile lists as k_gemm_mfma (8 x 8 super-tiles, 64 x 128 half tiles at the
-//     end), two workgroups per CU; the ring runs ACROSS tiles: the first two chunks of the next tile are requested during
-//     the last two steps of this one and travel under the epilogue.
-// Sigma stays exactly symmetric: strictly-lower tiles are mirrored, diagonal tiles store their lower triangle twice.
+//   * persistent grid on a host-ordered list of CANONICAL 128 x 128 tiles (block of the row >= block of the column; diagonal
+//     tiles first, then 8 x 8 super-tiles), two workgroups per CU; the ring runs ACROSS tiles: the next list entry is drawn
+//     while the tile computes, and the first two chunks of the next tile are requested during the last two steps of this one
+//     and travel under the epilogue.
+// Every element pair {r, c} of Sigma is ONE sum (k_syrk_bf16x6 below), so Sigma stays exactly symmetric and the rows a rank
+// of a sharded filter holds are bit-identical to the plain filter's.
+// Measured (tools/syrk6_probe.hip, profiles/r5_syrk6_probe.txt): LDS reads + MFMAs alone 250 TF fp32-equivalent (1.5 PF
+// executed: the clock the chip holds under this load, not the issue stream, is the ceiling); + LDS-DMA 200-215; + the C
+// tile 145-190 (K = 384 .. 1152) against 100-118 for k_gemm_mfma on the same launches.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "ekf_dense.hpp"

@@ -35,7 +35,10 @@ extern "C" {
 /* 3 (round 3): + ekf_export_points_table, ekf_get_feature_ids, ekf_set_feature_meta, ekf_num_archived,
  * EKF_OPT_FUSED_LAUNCHES; the sharded filter accepts the whole update flow; - ekf_debug_flow_trace */
 /* 4 (round 4): + EKF_OPT_W_RECOMPUTE (default on), ekf_get_chunk_plan; the map getters are collective on a sharded filter */
-#define EKF_ABI_VERSION 4
+/* 5 (round 5): no new entry points; EKF_OPT_SPLIT_BF16 is ON by default (large maps: covariance downdate on the bf16 matrix
+ * pipe at fp32 accuracy) and applies to the sharded step too; the sharded step runs the sequential form (EKF_OPT_W_RECOMPUTE);
+ * the gathered diagonal blocks of the map getters stay valid between two filter steps */
+#define EKF_ABI_VERSION 5
 
 typedef struct ekf_filter ekf_filter;
 
@@ -86,10 +89,15 @@ enum ekf_option {
    * second, CU-masked stream beside the serial chain; k >= 2 = k equal chunks;
    * -1 (default): as 1 when the chain has at least 8 block steps (m >= 1024), else as 0. */
   EKF_OPT_PIPELINE = 3,
-  /* 0 (default): every contraction in exact fp32 (v_mfma_f32_32x32x2_f32).  1: the covariance downdate of large
-   * maps runs on the bf16 matrix pipe with each fp32 operand split exactly into three bf16 values and the six
-   * products above 2^-25 |a||b| accumulated in fp32 (csrc/ekf_split.hpp): fp32-class accuracy, not bit-equal
-   * to the fp32 instruction.  fp32 filters only. */
+  /* 1 (default since round 5): the covariance downdate Sigma -= V_g V_g^T of large maps (at least 23 tile rows of 128: N >= ~480
+   * inverse-depth features on a 256-CU device) runs on the bf16 matrix pipe AT FP32 ACCURACY: each fp32 operand is split
+   * exactly into three bf16 values, a = a1 + a2 + a3, and the six products above 2^-25 |a||b| -- below half an ulp of the
+   * fp32 product -- are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (csrc/ekf_syrk6.hpp).  Every other contraction, every
+   * accumulation, the state and the covariance stay fp32.  Measured against the fp64 oracle the result is as close as the
+   * fp32 instruction's (tests/test_gpu_parity.py::test_split_bf16_downdate_is_fp32_accurate); it is not bit-equal
+   * to it.  Sigma stays exactly symmetric, and a rank of a sharded filter computes bit-identical rows (every element pair is
+   * one sum, whoever computes it).  0: every contraction on v_mfma_f32_32x32x2_f32 (the arithmetic of rounds 1-4).  fp32
+   * filters only; smaller maps and fp64 filters are not affected. */
   EKF_OPT_SPLIT_BF16 = 4,
   /* 0 (default: the reference's model -- the map is static, features carry no process noise).  v > 0: every
    * predict adds v x 1e-12 to the variance of every feature state (Sigma[i][i], i >= camera_dim): the "stabilising
