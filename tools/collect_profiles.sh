@@ -56,6 +56,7 @@ echo "diagonal factor + column-chain microbenchmarks"
 "$R/tools/chain_latency" > "$O/r5_chain_latency.txt"
 echo "sharded step on one rank over RCCL (world 1, forced collectives), plain row panel vs symmetric own block"
 for sym in 0 1; do EKF_SHARD_SYM=$sym python3 "$R/tools/shard_world1.py" 1000 60 2>/dev/null | tail -1 > "$O/r5_shard_world1_nccl_sym$sym.json"; done
+python3 "$R/tools/shard_world1.py" 4000 12 2>/dev/null | tail -1 > "$O/r5_shard_world1_nccl_n4000.json"
 echo "rccl_smoke rehearsal (gloo, 2 / 3 / 4 ranks on the one GPU)"
 : > "$O/r5_rccl_smoke_gloo.txt"
 for g in 2 3 4; do python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $g --master-addr 127.0.0.1 --master-port 2954$g "$R/tools/rccl_smoke.py" --backend gloo 2>&1 | grep "rccl_smoke" >> "$O/r5_rccl_smoke_gloo.txt"; done
