@@ -1193,12 +1193,13 @@ struct Filter : FilterBase {
       // downdate has every CU and the largest K (tools/knob_ab.py: 1.169 ms against 1.187 with 3 / 8 / 16, 1.216 with 3 / 6)
       // round 5 (EKF_OPT_SPLIT_BF16, the downdate 1.5 x faster): the second stream has slack beside the chain, so one more
       // chunk pays -- the exposed first chunk and the exposed last chunk both get shorter (tools/knob_ab.py, ms per step):
-      //   16 steps (N = 1000): 1.063 with 3 / 7 / 16, 1.049 with 3 / 7 / 12 / 16, 1.032 with 2 / 6 / 11 / 16; five chunks 1.09-1.11
+      //   16 steps (N = 1000): 1.063 with 3 / 7 / 16; four chunks: a plateau of 1.01-1.04 over {2, 3} x {5 .. 8} x {10 .. 13} (a sweep of 32
+      //   plans), 3 / 7 / 11 / 16 at its low end (1.013-1.018 against 1.026-1.034 for 2 / 6 / 11 / 16); five chunks 1.05-1.11
       //   32 steps (N = 2000): 5.28 with 4 / 13 / 32, 5.05 with 4 / 12 / 22 / 32, 5.09 with five chunks
       //   63 steps (N = 4000): 35.96 with 5 / 25 / 63, 34.97 with 4 / 16 / 36 / 63, 34.27 with 4 / 14 / 30 / 46 / 63
       const bool split = kIsF32 && opt_split_bf16 && opt_mfma;
       if (split && nsteps >= 12) {
-        static const double f4[4] = {2.0 / 16, 6.0 / 16, 11.0 / 16, 1.0}, f4l[4] = {4.0 / 32, 12.0 / 32, 22.0 / 32, 1.0},
+        static const double f4[4] = {3.0 / 16, 7.0 / 16, 11.0 / 16, 1.0}, f4l[4] = {4.0 / 32, 12.0 / 32, 22.0 / 32, 1.0},
                             f5[5] = {4.0 / 63, 14.0 / 63, 30.0 / 63, 46.0 / 63, 1.0};
         const int ng = nsteps >= 48 ? 5 : 4;
         const double* fr = nsteps >= 48 ? f5 : (nsteps >= 32 ? f4l : f4);
