@@ -1175,7 +1175,7 @@ struct Filter : FilterBase {
 
   // Chunk ends (in block steps) of the factorisation.  One chunk = the plain algorithm (the strip is the
   // whole inverse); several chunks when the chain is long enough to be worth hiding.
-  int plan_chunks(int nsteps, int* cend) const {
+  int plan_chunks(int nsteps, int* cend, bool sharded = false) const {
     const bool pipe = (opt_pipeline < 0) ? (nsteps >= 8) : (opt_pipeline != 0);
     if (!pipe || nsteps < 2 || !stream_b) { cend[0] = nsteps; return 1; }
     if (env_nchunks > 0 && env_chunks[env_nchunks - 1] == nsteps) {
@@ -1199,7 +1199,11 @@ struct Filter : FilterBase {
       //   63 steps (N = 4000): 35.96 with 5 / 25 / 63, 34.97 with 4 / 16 / 36 / 63, 34.27 with 4 / 14 / 30 / 46 / 63
       const bool split = kIsF32 && opt_split_bf16 && opt_mfma;
       if (split && nsteps >= 12) {
-        static const double f4[4] = {3.0 / 16, 7.0 / 16, 11.0 / 16, 1.0}, f4l[4] = {4.0 / 32, 12.0 / 32, 22.0 / 32, 1.0},
+        // (the sharded step, whose second stream also carries the gathers in series: 2 / 6 / 11 / 16 -- world 1 with forced
+        // collectives 1.305 ms against 1.354 with 3 / 7 / 11 / 16)
+        static const double f4p[4] = {3.0 / 16, 7.0 / 16, 11.0 / 16, 1.0}, f4s[4] = {2.0 / 16, 6.0 / 16, 11.0 / 16, 1.0};
+        const double* f4 = sharded ? f4s : f4p;
+        static const double f4l[4] = {4.0 / 32, 12.0 / 32, 22.0 / 32, 1.0},
                             f5[5] = {4.0 / 63, 14.0 / 63, 30.0 / 63, 46.0 / 63, 1.0};
         const int ng = nsteps >= 48 ? 5 : 4;
         const double* fr = nsteps >= 48 ? f5 : (nsteps >= 32 ? f4l : f4);
@@ -2761,7 +2765,7 @@ struct Filter : FilterBase {
         for (int g = 0; g < env_nchunks; ++g) cend[g] = env_chunks[g];
         nchunks = env_nchunks;
       } else if (sh_world <= 1 && nsteps >= 8) {
-        nchunks = plan_chunks(nsteps, cend);                 // one rank: the plain path's plan (3 / 7 / 16 sixteenths)
+        nchunks = plan_chunks(nsteps, cend, true);           // one rank: the plain path's plan with an earlier first cut
       } else {
         // chunk count by world size: every chunk costs a pass over the remaining columns of W and re-reads the Sigma
         // panel, and a rank's share of that work is 1 / world -- two ranks afford 4 chunks, four and more 8
