@@ -6,7 +6,7 @@ import os
 import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libekfslam_hip.so")
+LIB_PATH = os.environ.get("EKF_LIB_PATH") or os.path.join(HERE, "lib", "libekfslam_hip.so")   # (EKF_LIB_PATH: an A/B build, tools/ only)
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "ekf_monoslam.h")
 
 EKF_F32, EKF_F64 = 0, 1
@@ -93,6 +93,7 @@ _PROTOS = {
     "ekf_get_state": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "ekf_set_state": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "ekf_get_sigma_block": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ekf_peek_workspace": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ekf_set_sigma_block": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ekf_covariance_parameter": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "ekf_feature_xyz": (C.c_int, [_P, C.c_int, _P, _P]),

@@ -84,6 +84,7 @@ struct FilterBase {
   virtual int get_state(void*, int, int) = 0;
   virtual int set_state(const void*, int, int) = 0;
   virtual int get_sigma(void*, int, int, int, int) = 0;
+  virtual int peek_work(int, void*, int, int, int, int) = 0;
   virtual int set_sigma(const void*, int, int, int, int) = 0;
   virtual int covariance_parameter(double*) = 0;
   virtual int check_invariants(double*, double*, double*) = 0;
@@ -1760,6 +1761,19 @@ struct Filter : FilterBase {
       for (int c = 0; c < cols; ++c) o[(size_t)c * rows + r] = tmp[(size_t)r * cols + c];
     return rcs;
   }
+  // diagnostics (tools/determinism_probe_sharded.py): a block of the update's workspace as the last update left it --
+  // which = 0: W (the columns of every chunk as the solve read them), 1: V = W L^-T; row-major rows x cols
+  int peek_work(int which, void* out, int r0, int c0, int rows, int cols) override {
+    HIPCHK(hipSetDevice(device));
+    if (which < 0 || which > 1) FAIL(EKF_ERR_ARG, "workspace id out of range");
+    if (r0 < 0 || c0 < 0 || rows < 0 || cols < 0 || r0 + rows > n_pad + NB() || c0 + cols > ldy)
+      FAIL(EKF_ERR_ARG, "workspace block out of range");
+    if (rows == 0 || cols == 0) return EKF_OK;
+    HIPCHK(hipDeviceSynchronize());
+    const T* src = (which == 0 ? d_W : d_V) + (size_t)r0 * ldy + c0;
+    HIPCHK(hipMemcpy2D(out, (size_t)cols * sizeof(T), src, (size_t)ldy * sizeof(T), (size_t)cols * sizeof(T), rows, hipMemcpyDeviceToHost));
+    return EKF_OK;
+  }
   int set_sigma(const void* in, int r0, int c0, int rows, int cols) override {
     HIPCHK(hipSetDevice(device));
     if (r0 < 0 || c0 < 0 || rows < 0 || cols < 0 || r0 + rows > n || c0 + cols > n)
@@ -2219,6 +2233,8 @@ struct Filter : FilterBase {
   // every other tile -- the ragged first / last row tile of the panel (it holds foreign rows), the columns of other
   // ranks -- is a plain tile.  Row tiles are relative to p0, column tiles absolute.
   int opt_shard_sym = 1;                                   // EKF_SHARD_SYM=0: the plain row panel (A/B)
+  int dbg_sync = 0;                                        // EKF_DEBUG_SYNC (bisecting an ordering problem): device synchronisation at 1 the end of
+                                                           // the sharded update, 2 the end of every chunk, 4 its start, 8 the end of the sharded predict
   int* d_panel_tiles = nullptr;
   size_t panel_tiles_cap = 0;
   int panel_ntiles = 0;
@@ -2593,6 +2609,7 @@ struct Filter : FilterBase {
     sh_on = true;
     if (const char* e = getenv("EKF_SHARD_FORCE_COLLECTIVE")) sh_force = (atoi(e) != 0) && fn != nullptr;
     if (const char* e = getenv("EKF_SHARD_SYM")) opt_shard_sym = atoi(e);
+    if (const char* e = getenv("EKF_DEBUG_SYNC")) dbg_sync = atoi(e);
     if (!stream_g) {
       HIPCHK(hipStreamCreateWithFlags(&stream_g, hipStreamNonBlocking));
       for (auto& e : ev_gath) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -2702,6 +2719,7 @@ struct Filter : FilterBase {
     have_update = false;
     have_meas = true;
     have_sd = false;
+    if (dbg_sync & 8) HIPCHK(hipDeviceSynchronize());
     return launch_blur();                                  // predicted blur of every template (replicated, like the templates)
   }
 
@@ -2725,6 +2743,7 @@ struct Filter : FilterBase {
     const int nb = NB();
     int m = 0, m_pad = 0;
     const int npad_live = round_up(n, nb);
+    if (dbg_sync & 4) HIPCHK(hipDeviceSynchronize());
     // nu (replicated), W rows {camera, own}, own rows of S, "reassemble S"
     int rc = shard_build_ws(idx, M, plane, d_zz, &m, &m_pad);
     if (rc) return rc;
@@ -2926,6 +2945,7 @@ struct Filter : FilterBase {
                                                       s0, s1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, r0);
             }
           }
+          if (dbg_sync & 2) HIPCHK(hipDeviceSynchronize());
           continue;
         }
       }
@@ -2989,6 +3009,7 @@ struct Filter : FilterBase {
     have_update = true;
     have_meas = false;
     ++frame_seq;
+    if (dbg_sync & 1) HIPCHK(hipDeviceSynchronize());
     return EKF_OK;
   }
 
@@ -3183,6 +3204,10 @@ int ekf_get_feature_layout(const ekf_filter* f, int* p, int* c) { IMPL_OR_ARG(f)
 
 int ekf_get_state(ekf_filter* f, void* out, int off, int cnt) { IMPL_OR_ARG(f); if (cnt > 0 && !out) return EKF_ERR_ARG; return f->impl->get_state(out, off, cnt); }
 int ekf_set_state(ekf_filter* f, const void* in, int off, int cnt) { IMPL_OR_ARG(f); MUTATES(f); if (cnt > 0 && !in) return EKF_ERR_ARG; return f->impl->set_state(in, off, cnt); }
+int ekf_peek_workspace(ekf_filter* f, int which, void* out, int r0, int c0, int rows, int cols) {
+  IMPL_OR_ARG(f);
+  return f->impl->peek_work(which, out, r0, c0, rows, cols);
+}
 int ekf_get_sigma_block(ekf_filter* f, void* out, int r0, int c0, int rows, int cols) {
   IMPL_OR_ARG(f);
   if (!out) return EKF_ERR_ARG;

@@ -349,6 +349,12 @@ class VSlamFilter:
         self._check(self._lib.ekf_get_sigma_block(self._h, self._ptr(out), r0, c0, rows, cols))
         return out.T.copy()
 
+    def peekWorkspace(self, which, r0, c0, rows, cols):
+        """Diagnostics: rows x cols of W (which = 0) or V (1) as the last update left them (ekf_peek_workspace)."""
+        out = np.zeros((rows, cols), self.dtype)
+        self._check(self._lib.ekf_peek_workspace(self._h, int(which), self._ptr(out), r0, c0, rows, cols))
+        return out
+
     def getFullSigma(self):
         n = self.stateDim()
         return self.getSigmaBlock(0, 0, n, n)

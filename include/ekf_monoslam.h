@@ -291,6 +291,10 @@ int ekf_set_state(ekf_filter* f, const void* in, int offset, int count);
  * RosVSLAMRansac.cpp:171-183). Column-major rows x cols. */
 int ekf_get_sigma_block(ekf_filter* f, void* out, int r0, int c0, int rows, int cols);
 int ekf_set_sigma_block(ekf_filter* f, const void* in, int r0, int c0, int rows, int cols);
+/* Diagnostics only (no reference counterpart; tools/determinism_probe_sharded.py): a block of the workspace of the LAST
+ * update, row-major rows x cols in the filter's dtype.  which = 0: W = Sigma H^T as the triangular solves read it,
+ * 1: V = W L^-T (the factor of the covariance downdate).  Rows: state rows, then the padding; columns: 2 x list slot. */
+int ekf_peek_workspace(ekf_filter* f, int which, void* out, int r0, int c0, int rows, int cols);
 /* Covariance_Parameter (vR.cpp:841-866): trace of Sigma[0:7,0:7]. */
 int ekf_covariance_parameter(ekf_filter* f, double* out);
 /* Invariants of the device-resident covariance, evaluated on the device (no n^2 copy): max |Sigma| outside the live
