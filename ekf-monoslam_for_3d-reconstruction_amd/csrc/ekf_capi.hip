@@ -1508,9 +1508,9 @@ struct Filter : FilterBase {
       bool split_now = false;
       if constexpr (kIsF32)
         split_now = opt_split_bf16 && opt_mfma && tile == 128 && tri_count >= num_cus && counter_next + 8 <= kQueueCounters;
-      const bool row_rider = split_now && recompute && opt_row_gemv && c1 < m_pad && !fuse;   // rides in the k_split_image launch below
+      const bool row_rider = split_now && recompute && opt_row_gemv && c1 < m_pad && !fuse;   // rides in the k_syrk_bf16x6 launch below
       if (row_rider) {
-        // (nothing here: the row goes with the plane image)
+        // (nothing here: the row goes with the downdate's launch)
       } else if (c1 < m_pad && !fuse && recompute) {
         // only the innovation row (row npad_live of [W; nu^T]) is updated right-looking: nu^T[c1:] -= y_g^T L[c1:, g]^T
         Scope sc(this, KID_WUPDATE, ss);
@@ -1556,22 +1556,20 @@ struct Filter : FilterBase {
           if (!d_Vimg) HIPCHK(hipMalloc(&d_Vimg, (size_t)(n_pad + 128) * ldy * 6));
           {
             Scope sc(this, KID_MISC, ss);
-            const int gy = width / 16;
-            const int xr = row_rider ? ((m_pad - c1 + 255) / 256 + gy - 1) / gy : 0;      // extra x blocks of the rider
-            dim3 grid(npad_live / 128 + xr, gy);
-            if (row_rider)
-              k_split_image<<<grid, 256, 0, ss>>>(d_V, ldy, npad_live, c0, width, d_Vimg, ldy / 16, d_V + (size_t)npad_live * ldy + c0,
-                                                  Y + (size_t)c1 * ldy + c0, ldy, d_W + (size_t)npad_live * ldy + c1, m_pad - c1);
-            else
-              k_split_image<<<grid, 256, 0, ss>>>(d_V, ldy, npad_live, c0, width, d_Vimg, ldy / 16);
+            dim3 grid(npad_live / 128, width / 16);
+            k_split_image<<<grid, 256, 0, ss>>>(d_V, ldy, npad_live, c0, width, d_Vimg, ldy / 16);
           }
           Scope sc(this, KID_DOWNDATE, ss);
           if (sc.on) prof_work[KID_DOWNDATE] += double(n) * n * (std::min(c1, m) - std::min(c0, m));
           Syrk6Args a{d_Vimg, ldy / 16, c0 / 16, width / 16, S(), ld, d_tilemap + tri6_off, tri_count, d_counters + counter_next,
                       0, 0, INT_MAX};
+          if (row_rider) {
+            a.ry = d_V + (size_t)npad_live * ldy + c0; a.rL = Y + (size_t)c1 * ldy + c0; a.rldl = ldy;
+            a.rnu = d_W + (size_t)npad_live * ldy + c1; a.rcols = m_pad - c1; a.rK = width; a.nrider = (m_pad - c1 + 255) / 256;
+          }
           counter_next += 8;
           const int wgs = 2 * (overlap ? (num_cus - reserved_cus) : num_cus);
-          k_syrk_bf16x6<0><<<std::min(tri_count, wgs), 256, 0, ss>>>(a);
+          k_syrk_bf16x6<0><<<a.nrider + std::min(tri_count, wgs), 256, 0, ss>>>(a);
           split_done = true;
         }
       }
@@ -2815,7 +2813,19 @@ struct Filter : FilterBase {
     if constexpr (kIsF32)                                  // (the plain path's rule: the lower tiles of the WHOLE matrix fill the chip)
       shard_split = opt_split_bf16 && opt_mfma && nb == 128 && (npad_live / 128) * (npad_live / 128 + 1) / 2 >= num_cus;
     if (shard_split) { rc = ensure_shard_syrk_list(r0, r1, npad_live); if (rc) return rc; }
+    bool sh_row_pending = false;                           // (sequential form) the innovation row still waits for chunk [c0, c1)
+    auto row_update_alone = [&](int c0, int c1, hipStream_t ss) {
+      if constexpr (kIsF32) {
+        Scope sc(this, KID_WUPDATE, ss);
+        k_innov_row_update<<<(m_pad - c1 + 63) / 64, 64, 0, ss>>>(d_V + (size_t)npad_live * ldy + c0, d_Y + (size_t)c1 * ldy + c0, ldy,
+                                                                  d_W + (size_t)npad_live * ldy + c1, m_pad - c1, c1 - c0);
+      }
+    };
     auto downdate_chunk = [&](int c0, int c1, hipStream_t ss) -> int {
+      if (sh_row_pending && !(kIsF32 && shard_split && counter_next + 8 <= kQueueCounters)) {
+        row_update_alone(c0, c1, ss);
+        sh_row_pending = false;
+      }
       if constexpr (kIsF32) {
         if (shard_split && counter_next + 8 <= kQueueCounters) {
           // EKF_OPT_SPLIT_BF16: V_g (every row: the gather is done) -> plane image, then ONE launch over the canonical tiles
@@ -2831,10 +2841,16 @@ struct Filter : FilterBase {
             if (sc.on) prof_work[KID_DOWNDATE] += 2.0 * 128 * 128 * shard_syrk_n * double(std::min(c1, m) - std::min(c0, m));
             Syrk6Args a{d_Vimg, ldy / 16, c0 / 16, (c1 - c0) / 16, S(), ld, d_shard_syrk, shard_syrk_n, d_counters + counter_next,
                         camera_dim, r0, r1};
+            if (sh_row_pending) {
+              a.ry = d_V + (size_t)npad_live * ldy + c0; a.rL = d_Y + (size_t)c1 * ldy + c0; a.rldl = ldy;
+              a.rnu = d_W + (size_t)npad_live * ldy + c1; a.rcols = m_pad - c1; a.rK = c1 - c0; a.nrider = (m_pad - c1 + 255) / 256;
+              sh_row_pending = false;
+            }
             counter_next += 8;
             const int wgs = 2 * ((ss == stream_b) ? (num_cus - reserved_cus) : num_cus);
-            k_syrk_bf16x6<0><<<std::min(shard_syrk_n, wgs), 256, 0, ss>>>(a);
+            k_syrk_bf16x6<0><<<a.nrider + std::min(shard_syrk_n, wgs), 256, 0, ss>>>(a);
           }
+          if (sh_row_pending) { row_update_alone(c0, c1, ss); sh_row_pending = false; }
           return EKF_OK;
         }
       }
@@ -2925,11 +2941,8 @@ struct Filter : FilterBase {
             rc = exchange_rows(d_V, ldy, rtab, c0, width, stream, KID_GATHER_V);
             if (rc) return rc;
           }
-          if (c1 < m_pad) {
-            Scope sc(this, KID_WUPDATE, ss);                 // nu^T[c1:] -= y_g^T L[c1:, g]^T (replicated, every rank)
-            k_innov_row_update<<<(m_pad - c1 + 63) / 64, 64, 0, ss>>>(d_V + (size_t)npad_live * ldy + c0, Y + (size_t)c1 * ldy + c0, ldy,
-                                                                      d_W + (size_t)npad_live * ldy + c1, m_pad - c1, width);
-          }
+          // nu^T[c1:] -= y_g^T L[c1:, g]^T (replicated, every rank): rides in the downdate's launch when there is one
+          sh_row_pending = c1 < m_pad;
           rc = downdate_chunk(c0, c1, ss);
           if (rc) return rc;
           if (gi + 1 < nchunks) {

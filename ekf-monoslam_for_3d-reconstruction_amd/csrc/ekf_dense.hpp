@@ -18,6 +18,7 @@ namespace ekf {
 // ---------------------------------------------------------------------------------------
 // nu = z - h for the measured list (+ plane rows: 0 - mu[{1,4,6}], vR.cpp:1257-1260).
 // ---------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kQueueCounters = 256;              // work-queue heads of the queued launches of one update (8 ints apart)
 
 // A measured list read from DEVICE memory (ekf_update_device) cannot be checked on the host: an entry outside
@@ -133,6 +134,31 @@ __global__ void k_sigma_ht(const T* __restrict__ S, int ld, int n,
       }
     }
   }
+}
+
+// One column of the right-looking update of the innovation row, nu[c] -= sum_k y[k] L[c][k] over a chunk's K columns: a serial
+// fmaf chain IN THE ORDER THE TILE GEMM ADDS THEM (k_gemm_mfma: within every group of eight k the four
+// v_mfma_f32_32x32x2_f32 of a fragment take k = {0, 4}, {1, 5}, {2, 6}, {3, 7}), then C' = fma(-1, acc, C): the same bits as
+// the 64 x 128 tile launch it replaced in round 5.  Used by k_innov_row_update and by the workgroups that ride in k_syrk_bf16x6.
+__device__ __forceinline__ void innov_row_column(const float* __restrict__ y, const float* __restrict__ Lr, int K,
+                                                 float* __restrict__ nu_c) {
+  float acc = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    f32x4 b[8], a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      b[u] = *reinterpret_cast<const f32x4*>(Lr + k0 + 4 * u);
+      a[u] = *reinterpret_cast<const f32x4*>(y + k0 + 4 * u);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc = __builtin_fmaf(a[2 * s][e], b[2 * s][e], acc);            // k = 8 s + e
+        acc = __builtin_fmaf(a[2 * s + 1][e], b[2 * s + 1][e], acc);    // k = 8 s + 4 + e
+      }
+  }
+  *nu_c = __builtin_fmaf(-1.f, acc, 1.f * *nu_c);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -547,7 +573,6 @@ __global__ void __launch_bounds__(256) k_gemm_valu(GemmArgs g) {
 // MFMA e multiplies k = 8s + 4h + e, the same permutation on A and B, so the sum is exact.
 // NN mode stages B by 4x4 register transposes of row-major [k][col] quads.
 // ---------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int ROLE, bool BT, int TM = 128, int TN = 128, bool S2 = false>
@@ -1905,34 +1930,16 @@ k_update_oneblock_small(const float* __restrict__ W, int ldw, const float* __res
 
 // ---------------------------------------------------------------------------------------
 // Right-looking update of the innovation row alone, nu^T[c1:] -= y_g^T L[c1:, g]^T (the sequential form of the chunked
-// update keeps W by re-evaluation; of [W; nu^T] only this row is still updated by the factor): one lane per column, a serial
-// fmaf chain over the chunk's K columns IN THE ORDER THE TILE GEMM ADDS THEM (k_gemm_mfma: within every group of eight k the
-// four v_mfma_f32_32x32x2_f32 of a fragment take k = {0, 4}, {1, 5}, {2, 6}, {3, 7}), then C' = fma(-1, acc, C) -- the
-// same bits as the 64 x 128 tile launch it replaces (26 tiles, one K loop each: 20-29 us of latency at N = 1000, against
-// ~5 us here).  L rows are walked by 16-byte loads that stay in L1 (64 rows x 128 B per workgroup).
+// update keeps W by re-evaluation; of [W; nu^T] only this row is still updated by the factor): one lane per column
+// (innov_row_column above) -- the same bits as the 64 x 128 tile launch it replaced (26 tiles, one K loop each: 20-29 us of
+// latency at N = 1000, against ~5 us here).  L rows are walked by 16-byte loads that stay in L1 (64 rows x 128 B per
+// workgroup).  The stand-alone launch: chunks whose downdate does not run in k_syrk_bf16x6 (whose launch carries it).
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_innov_row_update(const float* __restrict__ y, const float* __restrict__ L, int ldl,
                                                         float* __restrict__ nu, int cols, int K) {
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (c >= cols) return;
-  const float* Lr = L + (size_t)c * ldl;
-  float acc = 0.f;
-  for (int k0 = 0; k0 < K; k0 += 32) {
-    f32x4 b[8], a[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      b[u] = *reinterpret_cast<const f32x4*>(Lr + k0 + 4 * u);
-      a[u] = *reinterpret_cast<const f32x4*>(y + k0 + 4 * u);
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc = __builtin_fmaf(a[2 * s][e], b[2 * s][e], acc);            // k = 8 s + e
-        acc = __builtin_fmaf(a[2 * s + 1][e], b[2 * s + 1][e], acc);    // k = 8 s + 4 + e
-      }
-  }
-  nu[c] = __builtin_fmaf(-1.f, acc, 1.f * nu[c]);
+  innov_row_column(y, L + (size_t)c * ldl, K, nu + c);
 }
 
 // ---------------------------------------------------------------------------------------

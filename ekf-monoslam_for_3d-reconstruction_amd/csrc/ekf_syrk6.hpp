@@ -38,35 +38,7 @@ constexpr int kS6Rec = 768;                    // 16-byte slots of one record (1
 // Image slot index of (row r, column c, plane p): ((r / 128) * nkc_total + c / 16) * 768 + p * 256 + ((c % 16) / 8) * 128 + r % 128.
 // One thread per (row, 8 columns): 32 B read, three 16-byte slots written (consecutive lanes = consecutive rows).
 __global__ void __launch_bounds__(256) k_split_image(const float* __restrict__ V, int ld, int rows, int c0, int width,
-                                                    s6_u32x4* __restrict__ img, int nkc_total,
-                                                    // optional rider (blocks blockIdx.x >= rows / 128): the right-looking update of the
-                                                    // innovation row, nu^T[c1:] -= y_g^T L[c1:, g]^T -- k_innov_row_update's sums
-                                                    // (ekf_dense.hpp), one lane per column, 256 columns per (x, y) block
-                                                    const float* __restrict__ ry = nullptr, const float* __restrict__ rL = nullptr,
-                                                    int rldl = 0, float* __restrict__ rnu = nullptr, int rcols = 0) {
-  if ((int)blockIdx.x >= (rows + 127) / 128) {
-    const int c = ((blockIdx.x - (rows + 127) / 128) * gridDim.y + blockIdx.y) * 256 + threadIdx.x;
-    if (c >= rcols) return;
-    const float* Lr = rL + (size_t)c * rldl;
-    float acc = 0.f;
-    for (int k0 = 0; k0 < width; k0 += 32) {
-      f32x4 b[8], a[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        b[u] = *reinterpret_cast<const f32x4*>(Lr + k0 + 4 * u);
-        a[u] = *reinterpret_cast<const f32x4*>(ry + k0 + 4 * u);
-      }
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc = __builtin_fmaf(a[2 * s][e], b[2 * s][e], acc);            // k = 8 s + e       (the tile GEMM's order)
-          acc = __builtin_fmaf(a[2 * s + 1][e], b[2 * s + 1][e], acc);    // k = 8 s + 4 + e
-        }
-    }
-    rnu[c] = __builtin_fmaf(-1.f, acc, 1.f * rnu[c]);
-    return;
-  }
+                                                    s6_u32x4* __restrict__ img, int nkc_total) {
   const int r = blockIdx.x * 128 + (threadIdx.x & 127);
   const int o0 = blockIdx.y * 2 + (threadIdx.x >> 7);          // octet (8 columns) inside the launch
   if (r >= rows || o0 * 8 >= width) return;
@@ -107,6 +79,12 @@ struct Syrk6Args {
   // Rows of Sigma that are VALID in this address space: [0, cam) and [v_lo, v_hi).  The plain filter: every row
   // (cam = 0, v_lo = 0, v_hi = INT_MAX).  A rank of a sharded filter: the camera rows and its own rows.
   int cam, v_lo, v_hi;
+  // Rider (nrider > 0): the first nrider workgroups of the launch do the right-looking update of the innovation row for
+  // the chunk whose V_g this launch downdates with, nu^T[c1:] -= y_g^T L[c1:, g]^T (innov_row_column, one lane per column,
+  // 256 columns per workgroup), and leave.  A chain of K fused multiply-adds per lane is 10-25 us of latency wherever it
+  // runs; here it runs beside 100+ us of tiles on <= 7 of the 448+ workgroup slots (round 5 first had it in k_split_image,
+  // in FRONT of the downdate: 7 -> 17 us on the second stream's critical path, three times per step).
+  const float* ry = nullptr; const float* rL = nullptr; int rldl = 0; float* rnu = nullptr; int rcols = 0, rK = 0, nrider = 0;
 };
 
 // Every element pair {r, c}, r >= c, is computed ONCE, as element (r, c) of its canonical tile (A block = the block of r,
@@ -161,6 +139,11 @@ __global__ void __launch_bounds__(256, 2) k_syrk_bf16x6(Syrk6Args g) {
     }
   };
 
+  if (g.nrider > 0 && (int)blockIdx.x < g.nrider) {
+    const int c = blockIdx.x * 256 + tid;
+    if (c < g.rcols) innov_row_column(g.ry, g.rL + (size_t)c * g.rldl, g.rK, g.rnu + c);
+    return;
+  }
   // ---- first tile -----------------------------------------------------------------------------------------------------
   if (tid == 0) {
     const int t = atomicAdd(g.counter, 1);
