@@ -936,6 +936,48 @@ def test_launch_structure_knobs_are_bit_identical(monkeypatch, knobs):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
+def test_plain_step_repeats_bit_for_bit():
+    """Work queues, two streams and persistent grids decide WHO computes a tile, never what it sums: two fresh filters fed the
+    same calls (six frames at N = 1000, a removal of 1 % of the features and as many adds behind the third) end on the
+    same bits, and the peeked workspace (W, V of the last update: ekf_peek_workspace) too.  (tools/determinism_probe.py
+    is the long version: 5440 frames without a deviation, profiles/r5_determinism_probe.txt.)"""
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from ekf_monoslam_amd import synthetic
+    cfg = pkg.kinect_config()
+    n_feat, frames = 1000, 6
+    px0, z = synthetic.measurement_stream(cfg, n_feat, frames, sigma_px=0.5)
+
+    def run():
+        f = pkg.VSlamFilter(cfg, capacity_features=n_feat + 16)
+        f.setDt(1.0 / 30.0)
+        for (u, v) in px0:
+            assert f.addFeature((u, v)) == 1
+        rng = np.random.default_rng(7)
+        sid = np.arange(n_feat)
+        for k in range(frames):
+            f.predict()
+            sel = np.nonzero(sid >= 0)[0].astype(np.int32)
+            f.update(z[k][sid[sel]].reshape(-1), sel)
+            if k == 2:
+                drop = sorted(rng.choice(n_feat, size=n_feat // 100, replace=False).tolist())
+                f.removeFeatures(drop)
+                sid = np.delete(sid, drop)
+                for _ in drop:
+                    assert f.addFeature((float(rng.uniform(20, 300)), float(rng.uniform(20, 220)))) == 1
+                sid = np.concatenate([sid, -np.ones(len(drop), np.int64)])
+        f.synchronize()
+        n, mp = f.stateDim(), (2 * int(np.sum(sid >= 0)) + 127) // 128 * 128
+        out = (f.getFullState(), f.getFullSigma(), f.peekWorkspace(0, 0, 0, n, mp), f.peekWorkspace(1, 0, 0, n, mp))
+        f.close()
+        return out
+
+    a, b = run(), run()
+    for x, y, name in zip(a, b, ("mu", "Sigma", "W", "V")):
+        assert np.array_equal(x, y), f"{name}: {int(np.sum(x != y))} entries differ between two runs of the same calls"
+    assert np.any(a[2] != 0) and np.any(a[3] != 0)
+
+
 def test_profile_reports_time_and_work_of_the_downdate():
     """EKF_OPT_PROFILE = 1 times the downdate launches with HIP events; ekf_profile_work reports their algorithmic
     flop: n^2 x the measured columns (symmetric half) plus, for the launch that carries its chunk's W update,
