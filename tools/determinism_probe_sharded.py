@@ -16,6 +16,7 @@ REPS = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 FRAMES = int(sys.argv[4]) if len(sys.argv) > 4 else 12
 EVERY = int(sys.argv[5]) if len(sys.argv) > 5 else 4
 PEEK = int(os.environ.get("PROBE_PEEK", "0"))
+LIGHT = int(os.environ.get("PROBE_LIGHT", "0"))        # compare mu, the camera rows of Sigma and (PROBE_PEEK) W / V only: shorter frames
 SLEEP = float(os.environ.get("PROBE_SLEEP", "0"))      # host pause behind every frame (does the timing between frames matter?)
 
 
@@ -63,8 +64,12 @@ def worker(rank, world, port):
                 sid = np.concatenate([sid, -np.ones(len(drop), np.int64)])
             info = sharded.shard_info(f)
             n = f.stateDim()
-            rows = np.r_[0:14, info.row_begin:info.row_end]
-            S = np.vstack([f.getSigmaBlock(0, 0, 14, n), f.getSigmaBlock(int(info.row_begin), 0, int(info.row_end - info.row_begin), n)])
+            if LIGHT:
+                rows = np.r_[0:14]
+                S = f.getSigmaBlock(0, 0, 14, n)
+            else:
+                rows = np.r_[0:14, info.row_begin:info.row_end]
+                S = np.vstack([f.getSigmaBlock(0, 0, 14, n), f.getSigmaBlock(int(info.row_begin), 0, int(info.row_end - info.row_begin), n)])
             mu_now = f.getFullState().copy()
             if SLEEP > 0:
                 time.sleep(SLEEP)
@@ -125,8 +130,12 @@ def worker(rank, world, port):
                         if f_i in set(fd0):
                             continue
                         i_post = i_pre - 6 * int(np.searchsorted(fdrop, f_i))
-                        ridx = int(np.flatnonzero(r0 == i_post)[0])
-                        srow = s0[ridx].astype(np.float32)
+                        if LIGHT:           # only the camera rows were kept: Sigma[i, 0:7] = Sigma[0:7, i] (the matrix is exactly symmetric)
+                            srow = np.zeros(s0.shape[1], np.float32)
+                            srow[:14] = s0[:14, i_post]
+                        else:
+                            ridx = int(np.flatnonzero(r0 == i_post)[0])
+                            srow = s0[ridx].astype(np.float32)
                         same_H = bool(np.array_equal(jac0[0], jac1[0]) and np.array_equal(jac0[1], jac1[1]))
                         print(f"      Jacobians of the two runs identical: {same_H}", flush=True)
                         for c in cls[:16]:
