@@ -340,8 +340,9 @@ int ekf_profile_reset(ekf_filter* f);
  * chunk -- exact-fp32 path, EKF_FUSE_WU -- that product is counted with it: under EKF_OPT_W_RECOMPUTE = 1 (the default)
  * only the innovation ROW is updated, 2 x 1 x (m - c1) x the chunk's columns; under = 0 the whole W, 2 (n + 1) (m - c1)
  * x those columns).  Where the other pieces of the sequential form are booked: the re-evaluation W'_h = Sigma' H_h^T under
- * "sigma_ht", a NON-fused innovation-row update (EKF_FUSE_WU = 0, EKF_OPT_SPLIT_BF16 = 1) under "w_update", the plane
- * image of V_g (EKF_OPT_SPLIT_BF16 = 1) under "misc". */
+ * "sigma_ht"; the innovation-row update under EKF_OPT_SPLIT_BF16 = 1 rides as the first workgroups of the downdate's
+ * launch (its time is inside "downdate_syrk", its 2 (m - c1) x columns flop are not counted), a stand-alone one
+ * (EKF_FUSE_WU = 0 on the exact-fp32 path, a rank that owns no rows) under "w_update"; the plane image of V_g under "misc". */
 int ekf_profile_work(ekf_filter* f, int kernel_id, double* flop);
 /* How the last ekf_update factored S (what the algorithmic flop of a step depends on): `block` = rows of a block step
  * (128 fp32 MFMA, 64 otherwise), ends[g] = block step at which column chunk g ends (the last one = m_pad / block),
