@@ -1,4 +1,4 @@
-"""The ONE tolerated deviation of the exact sharded-vs-plain comparisons (helpers.exact_or_anchor_glitch, DESIGN 7):
+"""The ONE tolerated deviation of the exact sharded-vs-plain comparisons (helpers.exact_or_anchor_glitch, DESIGN 6):
 what it lets through and what it does not."""
 import warnings
 

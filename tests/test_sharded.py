@@ -761,7 +761,7 @@ def test_hip_shard_n4000_resize_cadence_two_ranks_match_plain_path():
         assert nfeat == N and mu.shape == (n,) and np.all(np.isfinite(mu)) and pad == 0.0
         ref_rows = np.concatenate([flt.getSigmaBlock(int(r), 0, 1, n) for r in rows])
         # bit-identical after 101 frames and two resizes -- or the ONE documented deviation of this rig (ranks sharing a
-        # GPU: an anchor coordinate off by < 1e-7 about once in 400 updates, helpers.exact_or_anchor_glitch, DESIGN 7)
+        # GPU: an anchor coordinate off by < 1e-7 about once in 400 updates, helpers.exact_or_anchor_glitch, DESIGN 6)
         exact_or_anchor_glitch(f"rank {rank} (rows {rows[14]} .. {rows[-1]})", mu, mu_p, S_rows, ref_rows, rows)
         ranges.append(frange)
     assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == N
