@@ -104,6 +104,9 @@ _PROTOS = {
     "ekf_profile_reset": (C.c_int, [_P]),
     "ekf_profile_work": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
     "ekf_get_chunk_plan": (C.c_int, [_P, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ekf_launch_kinds": (C.c_int, []),
+    "ekf_launch_kind_name": (C.c_char_p, [C.c_int]),
+    "ekf_launch_count": (C.c_int, [_P, C.c_int, C.POINTER(C.c_longlong)]),
     "ekf_shard_configure": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "ekf_shard_get_info": (C.c_int, [_P, _P]),
     "ekf_shard_update": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),

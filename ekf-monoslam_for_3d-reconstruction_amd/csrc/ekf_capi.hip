@@ -56,6 +56,13 @@ static const char* kKernelNames[KID_COUNT] = {
     "solve_trmm",      "normalize_quat",  "add_feature",      "compact_transform",   "misc",
     "w_update", "allgather_h", "allgather_s", "allgather_v", "allgather_sigma"};
 
+// Which launch structure an update actually took (ekf_launch_count): host-side counters, always on, one increment per
+// launch.  The order is the ABI's `enum ekf_launch_kind`.
+static const char* kLaunchNames[EKF_LAUNCH_KINDS] = {
+    "downdate_bf16x6", "downdate_f32", "downdate_f32_fused_wu", "downdate_f32_half_tail", "downdate_f32_t64",
+    "row_rider", "row_gemv", "row_tile_gemm", "w_update_gemm", "w_recompute",
+    "chain_step_launches", "chain_persistent", "solve", "solve_two_groups", "update_oneblock", "update_allinone"};
+
 static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
 struct FilterBase {
@@ -93,6 +100,7 @@ struct FilterBase {
   virtual int profile_reset() = 0;
   virtual int profile_work(int, double*) = 0;
   virtual int chunk_plan(int*, int, int*, int*) = 0;
+  long long launch_cnt[EKF_LAUNCH_KINDS] = {};           // ekf_launch_count: since ekf_create / ekf_profile_reset
   virtual void* dev_mu() = 0;
   virtual void* dev_sigma(int*) = 0;
   virtual int export_points(void*, int) = 0;
@@ -1083,6 +1091,7 @@ struct Filter : FilterBase {
     if constexpr (kIsF32) {
       if (opt_mfma) {
         if constexpr (ROLE == ROLE_SOLVE) {
+          ++launch_cnt[solve_s2_now ? EKF_LAUNCH_SOLVE_TWO_GROUPS : EKF_LAUNCH_SOLVE];
           if (solve_s2_now) {
             k_gemm_mfma<ROLE, BT, TM, TN, true><<<grid, 512, 0, st>>>(g);
             return;
@@ -1313,6 +1322,7 @@ struct Filter : FilterBase {
       T* Dj = d_Dinv + (size_t)step * nb * nb;
       {
         Scope sc(this, KID_CHOL_DIAG, sc_);
+        ++launch_cnt[EKF_LAUNCH_CHAIN_STEP];
         if (nb == 128) {
           if constexpr (kIsF32)
             k_chol_diag_packed<><<<1, 1024, 0, sc_>>>(Ajj, ldy, Dj, d_status, std::max(1, std::min(8, (m - j + 15) / 16)));
@@ -1334,6 +1344,7 @@ struct Filter : FilterBase {
       if (!skip_panel) {
         Scope sc(this, KID_CHOL_PANEL, sc_);                 // P = Y[r0.., j:j+nb] * Linv_jj^T, in place
         T* P = Y + (size_t)r0 * ldy + j;
+        ++launch_cnt[EKF_LAUNCH_CHAIN_STEP];
         launch_panel(P, Dj, vrows, sc_);
       }
       const int tcols = m_pad - r0;
@@ -1341,6 +1352,7 @@ struct Filter : FilterBase {
         Scope sc(this, KID_CHOL_TRAILING, sc_);              // Y[r0.., r0:] -= P P_S^T; strip rows stop at c1
         const T* P = Y + (size_t)r0 * ldy + j;
         T* C = Y + (size_t)r0 * ldy + r0;
+        ++launch_cnt[EKF_LAUNCH_CHAIN_STEP];
         gemm<ROLE_TRAILING, false, 64, 64>(P, ldy, P, ldy, C, ldy, vrows, tcols, nb, T(-1), T(1), 1, r0, r0, 0, 0,
                                            sc_, nullptr, 0, m_pad, c1);
       }
@@ -1461,6 +1473,7 @@ struct Filter : FilterBase {
           const int nrb = npad_live / 64, nt64 = nrb * (nrb + 1) / 2;
           // small map: downdate and normalisation congruence in the same launch, one 64 x 64 tile of Sigma per workgroup
           allinone = nt64 <= num_cus && !prof_on(KID_DOWNDATE) && !prof_on(KID_NORMALIZE);
+          ++launch_cnt[allinone ? EKF_LAUNCH_UPDATE_ALLINONE : EKF_LAUNCH_UPDATE_ONEBLOCK];
           if (allinone)
             k_update_oneblock_small<<<nt64 + 1, 512, 0, ss>>>(d_W, ldy, d_Dinv, d_V, ldy, npad_live, mu(), n, d_scr + SCR_QOLD,
                                                              d_scr + SCR_QN, Zs, ldy, S(), ld, nt64);
@@ -1514,6 +1527,7 @@ struct Filter : FilterBase {
       } else if (c1 < m_pad && !fuse && recompute) {
         // only the innovation row (row npad_live of [W; nu^T]) is updated right-looking: nu^T[c1:] -= y_g^T L[c1:, g]^T
         Scope sc(this, KID_WUPDATE, ss);
+        ++launch_cnt[(kIsF32 && opt_row_gemv) ? EKF_LAUNCH_ROW_GEMV : EKF_LAUNCH_ROW_TILE_GEMM];
         if constexpr (kIsF32) {
           if (opt_row_gemv)
             k_innov_row_update<<<(m_pad - c1 + 63) / 64, 64, 0, ss>>>(d_V + (size_t)npad_live * ldy + c0, Y + (size_t)c1 * ldy + c0, ldy,
@@ -1525,6 +1539,7 @@ struct Filter : FilterBase {
                                              0, 0, ss);
       } else if (c1 < m_pad && !fuse) {
         Scope sc(this, KID_WUPDATE, ss);
+        ++launch_cnt[EKF_LAUNCH_W_UPDATE_GEMM];
         const int slots = 2 * (overlap ? num_cus - reserved_cus : num_cus);
         if (kIsF32 && opt_mfma && ((m_pad - c1) / 128) * ntr < slots)
           gemm<ROLE_WUPDATE, false, 64, 128>(d_V + c0, ldy, Y + (size_t)c1 * ldy + c0, ldy, d_W + c1, ldy, npad_live + nb,
@@ -1568,6 +1583,8 @@ struct Filter : FilterBase {
             a.rnu = d_W + (size_t)npad_live * ldy + c1; a.rcols = m_pad - c1; a.rK = width; a.nrider = (m_pad - c1 + 255) / 256;
           }
           counter_next += 8;
+          ++launch_cnt[EKF_LAUNCH_DOWNDATE_BF16X6];
+          if (row_rider) ++launch_cnt[EKF_LAUNCH_ROW_RIDER];
           const int wgs = 2 * (overlap ? (num_cus - reserved_cus) : num_cus);
           k_syrk_bf16x6<0><<<a.nrider + std::min(tri_count, wgs), 256, 0, ss>>>(a);
           split_done = true;
@@ -1587,6 +1604,7 @@ struct Filter : FilterBase {
                      d_tilemap, n2 + tri_count, d_counters + counter_next, 0, 0, 1,
                      Y + (size_t)c1 * ldy + c0, ldy, d_W + c1, ldy, n2, nr2, row2};
           counter_next += 8;
+          ++launch_cnt[EKF_LAUNCH_DOWNDATE_F32_FUSED_WU];
           const int wgs = 2 * (num_cus - reserved_cus);
           k_gemm_mfma<ROLE_DOWNDATE, false><<<std::min(g.ntiles, wgs), 256, 0, ss>>>(g);
           if (!recompute) HIPCHK(hipEventRecord(ev_wu, stream_b));
@@ -1594,6 +1612,10 @@ struct Filter : FilterBase {
       } else if (!split_done && !allinone) {
         Scope sc(this, KID_DOWNDATE, ss);                 // Sigma -= V_g V_g^T (lower tiles + mirror)
         if (sc.on) prof_work[KID_DOWNDATE] += double(n) * n * (std::min(c1, m) - std::min(c0, m));   // symmetric half, 2 flop per MAC
+        const bool t64 = kIsF32 && opt_mfma && tri_count < num_cus;
+        const bool half_tail = !t64 && kIsF32 && opt_mfma && ss != stream_b && trih_count > tri_count &&
+                               counter_next + 8 <= kQueueCounters;
+        ++launch_cnt[t64 ? EKF_LAUNCH_DOWNDATE_F32_T64 : (half_tail ? EKF_LAUNCH_DOWNDATE_F32_HALF_TAIL : EKF_LAUNCH_DOWNDATE_F32)];
         if (kIsF32 && opt_mfma && tri_count < num_cus)    // small map: 64 x 64 tiles, or most of the chip idles
           gemm<ROLE_DOWNDATE, false, 64, 64>(d_V + c0, ldy, d_V + c0, ldy, S(), ld, npad_live, npad_live, width, T(-1), T(1),
                                              2, 0, 0, 0, 0, ss, d_tilemap + tri64_off, tri64_count);
@@ -1612,6 +1634,7 @@ struct Filter : FilterBase {
           // over Sigma in all; the right-looking GEMM update W[:, c1:] -= V_g L[c1:, g]^T of every chunk
           // (2 n w_g (m - c1) flop) is not needed
           Scope sc(this, KID_SIGMA_HT, ss);
+          ++launch_cnt[EKF_LAUNCH_W_RECOMPUTE];
           const int s0 = c1 / 2, s1 = cend[gi + 1] * nb / 2;
           constexpr int RB = 8;
           dim3 grid((s1 - s0 + 127) / 128, (n + RB - 1) / RB);
@@ -2817,6 +2840,7 @@ struct Filter : FilterBase {
     auto row_update_alone = [&](int c0, int c1, hipStream_t ss) {
       if constexpr (kIsF32) {
         Scope sc(this, KID_WUPDATE, ss);
+        ++launch_cnt[EKF_LAUNCH_ROW_GEMV];
         k_innov_row_update<<<(m_pad - c1 + 63) / 64, 64, 0, ss>>>(d_V + (size_t)npad_live * ldy + c0, d_Y + (size_t)c1 * ldy + c0, ldy,
                                                                   d_W + (size_t)npad_live * ldy + c1, m_pad - c1, c1 - c0);
       }
@@ -2845,7 +2869,9 @@ struct Filter : FilterBase {
               a.ry = d_V + (size_t)npad_live * ldy + c0; a.rL = d_Y + (size_t)c1 * ldy + c0; a.rldl = ldy;
               a.rnu = d_W + (size_t)npad_live * ldy + c1; a.rcols = m_pad - c1; a.rK = c1 - c0; a.nrider = (m_pad - c1 + 255) / 256;
               sh_row_pending = false;
+              ++launch_cnt[EKF_LAUNCH_ROW_RIDER];
             }
+            ++launch_cnt[EKF_LAUNCH_DOWNDATE_BF16X6];
             counter_next += 8;
             const int wgs = 2 * ((ss == stream_b) ? (num_cus - reserved_cus) : num_cus);
             k_syrk_bf16x6<0><<<a.nrider + std::min(shard_syrk_n, wgs), 256, 0, ss>>>(a);
@@ -2858,6 +2884,7 @@ struct Filter : FilterBase {
         const Rows& rr = ranges[q];
         if (rr.count == 0) continue;
         Scope sc(this, KID_DOWNDATE, ss);
+        ++launch_cnt[EKF_LAUNCH_DOWNDATE_F32];
         if (q == 1 && sym_panel && counter_next + 8 <= kQueueCounters) {
           // the own panel as ONE queued launch over the listed tiles: interior x interior lower tiles + mirror, the rest plain
           if (sc.on) prof_work[KID_DOWNDATE] += 2.0 * 128 * 128 * panel_ntiles * double(std::min(c1, m) - std::min(c0, m));
@@ -2947,6 +2974,7 @@ struct Filter : FilterBase {
           if (rc) return rc;
           if (gi + 1 < nchunks) {
             Scope sc(this, KID_SIGMA_HT, ss);                // W'[rows, c1:c2) = Sigma'[rows, :] H^T, rows = camera + own
+            ++launch_cnt[EKF_LAUNCH_W_RECOMPUTE];
             const int s0 = c1 / 2, s1 = cend[gi + 1] * nb / 2;
             constexpr int RB = 8;
             dim3 g1((s1 - s0 + 127) / 128, (camera_dim + RB - 1) / RB);
@@ -2975,6 +3003,7 @@ struct Filter : FilterBase {
           if (rr.count == 0) continue;
           const size_t off = (size_t)rr.r0 * ldy;
           Scope sc(this, KID_WUPDATE, ss);
+          ++launch_cnt[EKF_LAUNCH_W_UPDATE_GEMM];
           gemm<ROLE_WUPDATE, false>(d_V + off + c0, ldy, Y + (size_t)c1 * ldy + c0, ldy, d_W + off + c1, ldy, rr.count,
                                     m_pad - c1, width, T(-1), T(1), 0, 0, 0, 0, 0, ss);
         }
@@ -3089,6 +3118,7 @@ struct Filter : FilterBase {
     memset(prof_ms, 0, sizeof(prof_ms));
     memset(prof_cnt, 0, sizeof(prof_cnt));
     memset(prof_work, 0, sizeof(prof_work));
+    memset(launch_cnt, 0, sizeof(launch_cnt));
     return EKF_OK;
   }
 };
@@ -3239,6 +3269,14 @@ int ekf_profile_kernels(void) { return ekf::KID_COUNT; }
 const char* ekf_profile_kernel_name(int kid) { return (kid >= 0 && kid < ekf::KID_COUNT) ? ekf::kKernelNames[kid] : ""; }
 int ekf_profile_read(ekf_filter* f, int kid, double* ms, long long* cnt) { IMPL_OR_ARG(f); return f->impl->profile_read(kid, ms, cnt); }
 int ekf_profile_reset(ekf_filter* f) { IMPL_OR_ARG(f); return f->impl->profile_reset(); }
+int ekf_launch_kinds(void) { return EKF_LAUNCH_KINDS; }
+const char* ekf_launch_kind_name(int kind) { return (kind >= 0 && kind < EKF_LAUNCH_KINDS) ? ekf::kLaunchNames[kind] : ""; }
+int ekf_launch_count(ekf_filter* f, int kind, long long* launches) {
+  IMPL_OR_ARG(f);
+  if (kind < 0 || kind >= EKF_LAUNCH_KINDS) { f->impl->err = "launch kind out of range"; return EKF_ERR_ARG; }
+  if (launches) *launches = f->impl->launch_cnt[kind];
+  return EKF_OK;
+}
 int ekf_profile_work(ekf_filter* f, int kid, double* flop) { IMPL_OR_ARG(f); return f->impl->profile_work(kid, flop); }
 int ekf_get_chunk_plan(ekf_filter* f, int* ends, int max_chunks, int* block, int* w_recompute) {
   if (!f || !f->impl) return 0;

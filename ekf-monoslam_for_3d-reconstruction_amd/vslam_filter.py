@@ -410,6 +410,16 @@ class VSlamFilter:
         k = int(self._lib.ekf_get_chunk_plan(self._h, ends, 8, C.byref(block), C.byref(wrec)))
         return block.value, [int(ends[g]) for g in range(min(k, 8))], bool(wrec.value)
 
+    def launch_counts(self):
+        """{launch kind: launches since creation / profile_reset} (ekf_launch_count): which launch structure the updates
+        of this handle actually took -- e.g. "downdate_bf16x6" against "downdate_f32"."""
+        out = {}
+        for k in range(self._lib.ekf_launch_kinds()):
+            cnt = C.c_longlong()
+            self._check(self._lib.ekf_launch_count(self._h, k, C.byref(cnt)))
+            out[self._lib.ekf_launch_kind_name(k).decode()] = int(cnt.value)
+        return out
+
     def profile_reset(self):
         self._check(self._lib.ekf_profile_reset(self._h))
 

@@ -38,7 +38,8 @@ extern "C" {
 /* 5 (round 5): no new entry points; EKF_OPT_SPLIT_BF16 is ON by default (large maps: covariance downdate on the bf16 matrix
  * pipe at fp32 accuracy) and applies to the sharded step too; the sharded step runs the sequential form (EKF_OPT_W_RECOMPUTE);
  * the gathered diagonal blocks of the map getters stay valid between two filter steps */
-#define EKF_ABI_VERSION 5
+/* 6 (round 6): + ekf_launch_kinds / ekf_launch_kind_name / ekf_launch_count (which launch structure an update took) */
+#define EKF_ABI_VERSION 6
 
 typedef struct ekf_filter ekf_filter;
 
@@ -350,6 +351,33 @@ int ekf_profile_work(ekf_filter* f, int kernel_id, double* flop);
  * rather than updated right-looking.  Returns the number of chunks (0 before the first update; at most `max_chunks`
  * entries are written). */
 int ekf_get_chunk_plan(ekf_filter* f, int* ends, int max_chunks, int* block, int* w_recompute);
+
+/* Which launch structure the updates of this handle actually took: one host-side counter per kind, incremented at the
+ * launch (always on, no device cost), cleared by ekf_profile_reset.  Diagnostics with no reference counterpart: the
+ * bit-identity tests of the tuning knobs assert with it that a knob really changed the launches, and bench.py reports the
+ * downdate kernel that ran instead of re-deriving the library's selection rule. */
+enum ekf_launch_kind {
+  EKF_LAUNCH_DOWNDATE_BF16X6 = 0,     /* k_syrk_bf16x6 (EKF_OPT_SPLIT_BF16 = 1, large maps)                              */
+  EKF_LAUNCH_DOWNDATE_F32,            /* k_gemm_mfma<DOWNDATE> 128 x 128, plain tile list (also every VALU / fp64 downdate) */
+  EKF_LAUNCH_DOWNDATE_F32_FUSED_WU,   /* ... carrying the chunk's right-looking update as its first tiles (EKF_FUSE_WU)  */
+  EKF_LAUNCH_DOWNDATE_F32_HALF_TAIL,  /* ... with 64 x 128 half tiles at the end of its list (EKF_SPLIT_TAIL)            */
+  EKF_LAUNCH_DOWNDATE_F32_T64,        /* 64 x 64 tiles (small maps)                                                      */
+  EKF_LAUNCH_ROW_RIDER,               /* innovation-row update as the first workgroups of k_syrk_bf16x6                  */
+  EKF_LAUNCH_ROW_GEMV,                /* ... as a stand-alone k_innov_row_update launch                                  */
+  EKF_LAUNCH_ROW_TILE_GEMM,           /* ... through the 64 x 128 tile GEMM (EKF_ROW_GEMV = 0)                           */
+  EKF_LAUNCH_W_UPDATE_GEMM,           /* right-looking update of all of W (EKF_OPT_W_RECOMPUTE = 0), stand-alone launch  */
+  EKF_LAUNCH_W_RECOMPUTE,             /* W' = Sigma' H^T re-evaluation launches (EKF_OPT_W_RECOMPUTE = 1)                */
+  EKF_LAUNCH_CHAIN_STEP,              /* launches of the per-block-step chain (diagonal factor, panel, trailing)          */
+  EKF_LAUNCH_CHAIN_PERSISTENT,        /* one launch per column chunk: the look-ahead chain kernel (round 6)              */
+  EKF_LAUNCH_SOLVE,                   /* triangular-solve launches on one wave group per tile                            */
+  EKF_LAUNCH_SOLVE_TWO_GROUPS,        /* ... on two wave groups per tile (EKF_SOLVE_S2)                                  */
+  EKF_LAUNCH_UPDATE_ONEBLOCK,         /* k_solve_state_oneblock (2 M + 3 <= 128)                                         */
+  EKF_LAUNCH_UPDATE_ALLINONE,         /* k_update_oneblock_small (... and a small map)                                   */
+  EKF_LAUNCH_KINDS
+};
+int ekf_launch_kinds(void);
+const char* ekf_launch_kind_name(int kind);
+int ekf_launch_count(ekf_filter* f, int kind, long long* launches);
 
 /* ---- multi-GPU: row-panel sharding, one process per GPU ----------------------------------------
  * Every rank holds the same filter (same calls in the same order on every rank: add / remove / convert / predict /

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert len(names) >= 35
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/ekf_monoslam.h but not exported"
-    assert lib.ekf_abi_version() == 5
+    assert lib.ekf_abi_version() == 6
 
 
 def test_prototypes_cover_the_header(pkg):
