@@ -16,6 +16,7 @@
 #include "ekf_dense.hpp"
 #include "ekf_image.hpp"
 #include "ekf_syrk6.hpp"
+#include "ekf_chain.hpp"
 #include "ekf_kernels.hpp"
 #include "ekf_shard.hpp"
 
@@ -222,6 +223,18 @@ struct Filter : FilterBase {
   float* d_score = nullptr;
   int* d_keep = nullptr;
   int opt_panel_direct = 1;                             // EKF_PANEL_DIRECT=0: panel through the general tile GEMM
+  // EKF_CHAIN_PERSISTENT=1: the chain as one look-ahead launch per column chunk (ekf_chain.hpp).  Bit-identical to the
+  // per-step launches and NOT faster (round 6, measured: profiles/r6_chain_persistent_trace.txt): 45-50 us per block
+  // step against 35-39 -- the critical workgroup moves ~360 KB per step through ONE CU, whose write-through stores run at
+  // 10-50 GB/s.  Off by default.
+  int opt_chain_persistent = 0;
+  ChainPlan chain_plan;
+  ChainTask* d_chain_tasks = nullptr;
+  unsigned* d_chain_flags = nullptr;
+  int chain_flags_cap = 0;
+  unsigned chain_epoch = 0;
+  unsigned* d_chain_trace = nullptr;                    // EKF_CHAIN_TRACE=1 (diagnostics, tools/chain_trace.py): per-task time stamps of the last update
+  static constexpr int kChainTraceCap = 1 << 16;
   int opt_solve_s2 = 1;                                 // EKF_SOLVE_S2: latency-bound solve launches on two wave groups (halves of K)
   bool solve_s2_now = false;
   // A solve launch of under ~one round of tiles is bounded by the K steps of its heaviest tile: two wave groups per
@@ -268,7 +281,8 @@ struct Filter : FilterBase {
                     d_flags, d_cflag, d_Jy, d_Yxyz, d_map_src, d_map_conv, d_Y, d_W, d_V, d_Dinv, d_z, d_midx,
                     d_status, d_tmp, d_K, d_tilemap, d_counters, d_ibuf, d_rmask, d_pts, d_tab,
                     d_frame, d_patch[0], d_patch[1], d_mpatch[0], d_mpatch[1], d_hb, d_zm, d_found, d_score, d_keep,
-                    d_Vimg, d_stage_send, d_stage_recv, d_archive, d_arch_idx, d_panel_tiles, d_shard_solve, d_shard_syrk};
+                    d_Vimg, d_stage_send, d_stage_recv, d_archive, d_arch_idx, d_panel_tiles, d_shard_solve, d_shard_syrk,
+                    d_chain_tasks, d_chain_flags, d_chain_trace};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int s = 0; s < kInSlots; ++s) { if (h_in[s]) hipHostFree(h_in[s]); if (ev_in[s]) hipEventDestroy(ev_in[s]); }
     if (h_pred) hipHostFree(h_pred);
@@ -420,6 +434,10 @@ struct Filter : FilterBase {
       if (const char* e = getenv("EKF_SOLVE_S2")) opt_solve_s2 = atoi(e);
       if (const char* e = getenv("EKF_FUSED_LAUNCHES")) opt_fused = atoi(e) ? 1 : 0;   // = EKF_OPT_FUSED_LAUNCHES, for A/B runs
       if (const char* e = getenv("EKF_PANEL_DIRECT")) opt_panel_direct = atoi(e);
+      if (const char* e = getenv("EKF_CHAIN_PERSISTENT")) opt_chain_persistent = atoi(e) ? 1 : 0;
+      if (const char* e = getenv("EKF_CHAIN_TRACE")) {
+        if (atoi(e)) HIPCHK(hipMalloc(&d_chain_trace, (size_t)(8 + 8 * kChainTraceCap) * sizeof(unsigned)));
+      }
       if (const char* e = getenv("EKF_SPLIT_TAIL")) opt_split_tail = atoi(e);
       if (const char* e = getenv("EKF_SPLIT_BF16")) opt_split_bf16 = atoi(e) ? 1 : 0;   // = EKF_OPT_SPLIT_BF16, for A/B runs
       if (const char* e = getenv("EKF_CHUNKS")) {           // tuning knob: chunk ends in block steps
@@ -450,6 +468,9 @@ struct Filter : FilterBase {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_diag<T, 64>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, diag_lds(64)));
     // (f32, NB = 128 uses k_chol_diag_packed: 66 KiB of static LDS)
+    if constexpr (kIsF32)
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_persistent),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLds));
     return EKF_OK;
   }
   static int diag_lds(int nb) { return 2 * nb * (nb + 1) * (int)sizeof(T); }
@@ -568,7 +589,7 @@ struct Filter : FilterBase {
     return with_status ? eval_status(st) : EKF_OK;
   }
   int eval_status(const int* st) {
-    if (st[0] || st[1] || st[3]) {
+    if (st[0] || st[1] || st[2] || st[3]) {
       HIPCHK(hipMemsetAsync(d_status, 0, 4 * sizeof(int), stream));
       if (st[3]) {
         // the arrival gate of k_predict_fused was left mid-count: every launch that could still add to it has to be
@@ -577,6 +598,13 @@ struct Filter : FilterBase {
         HIPCHK(hipMemsetAsync(d_status + 8, 0, sizeof(int), stream));
         opt_fused = 0;
         FAIL(EKF_ERR_DEVICE, "a bounded device-side wait gave up (fused launch); EKF_OPT_FUSED_LAUNCHES is now off for this filter");
+      }
+      if (st[2]) {
+        // a hand-over of the persistent chain kernel was never published within its bound: the launch gave up (every
+        // workgroup left); the per-step launches take over for this filter
+        opt_chain_persistent = 0;
+        chain_epoch = 0;
+        FAIL(EKF_ERR_DEVICE, "a bounded device-side wait gave up (persistent chain); EKF_CHAIN_PERSISTENT is now off for this filter");
       }
       if (st[1])
         FAIL(EKF_ERR_ARG, "ekf_update_device: a device-resident index is outside [0, N) or the list is not strictly "
@@ -1311,6 +1339,70 @@ struct Filter : FilterBase {
     return EKF_OK;
   }
 
+  // ---- the chain as ONE look-ahead launch per column chunk (ekf_chain.hpp) ------------------------------------------
+  bool chain_persistent_ok() const {
+    return kIsF32 && opt_mfma && opt_chain_persistent && (size_t)2 * ldy * ldy * sizeof(T) < ((size_t)1 << 31);
+  }
+  // Task lists of every launch of the chunk plan (cached until the plan changes), the hand-over words, and this update's epoch.
+  int chain_begin_update(int nblk, int nchunks, const int* cend) {
+    bool same = chain_plan.nblk == nblk && chain_plan.nchunks == nchunks;
+    for (int g = 0; same && g < nchunks; ++g) same = chain_plan.cend[g] == cend[g];
+    if (!same) {
+      build_chain_plan(chain_plan, nblk, nchunks, cend);
+      if (!validate_chain_plan(chain_plan)) {
+        chain_plan.nblk = 0;
+        FAIL(EKF_ERR_DEVICE, "internal: the task lists of the persistent chain do not complete with one worker per list");
+      }
+      HIPCHK(hipStreamSynchronize(stream));
+      if (stream_b) HIPCHK(hipStreamSynchronize(stream_b));
+      if (d_chain_tasks) HIPCHK(hipFree(d_chain_tasks));
+      d_chain_tasks = nullptr;
+      HIPCHK(hipMalloc(&d_chain_tasks, chain_plan.tasks.size() * sizeof(ChainTask)));
+      HIPCHK(hipMemcpy(d_chain_tasks, chain_plan.tasks.data(), chain_plan.tasks.size() * sizeof(ChainTask), hipMemcpyHostToDevice));
+      if (chain_plan.nflags > chain_flags_cap) {
+        if (d_chain_flags) HIPCHK(hipFree(d_chain_flags));
+        d_chain_flags = nullptr;
+        chain_flags_cap = chain_plan.nflags + 1024;
+        HIPCHK(hipMalloc(&d_chain_flags, (size_t)chain_flags_cap * sizeof(unsigned)));
+        chain_epoch = 0;
+      }
+    }
+    if (chain_epoch == 0 || chain_epoch >= (1u << (32 - kChainEpochShift)) - 2) {   // fresh words, or the epoch would wrap
+      HIPCHK(hipMemsetAsync(d_chain_flags, 0, (size_t)chain_flags_cap * sizeof(unsigned), stream));
+      chain_epoch = 0;
+    }
+    ++chain_epoch;
+    if (d_chain_trace) HIPCHK(hipMemsetAsync(d_chain_trace, 0, 8 * sizeof(unsigned), stream));
+    return EKF_OK;
+  }
+  // Launch gi of the plan: chunk gi's factor, panels and all but its last trailing update (+ the one chunk gi - 1 left).
+  // `whole_chip`: nothing else is running (chunk 0): one workgroup per CU; else the CUs the second stream leaves alone.
+  int chain_launch(int gi, int m, bool whole_chip, hipStream_t sc_) {
+    if (counter_next + 8 > kQueueCounters) FAIL(EKF_ERR_DEVICE, "internal: out of work-queue counters");
+    const ChainPlan::Launch& L = chain_plan.launch[gi];
+    ChainArgs a{};
+    if constexpr (kIsF32) { a.Y = d_Y; a.Dinv = d_Dinv; }
+    a.ldy = ldy;
+    a.y_bytes = (unsigned)((size_t)2 * ldy * ldy * sizeof(T));
+    a.dinv_bytes = (unsigned)((size_t)(ldy / 64) * 128 * 128 * sizeof(T));
+    a.status = d_status;
+    a.m = m;
+    a.s0 = gi ? chain_plan.cend[gi - 1] : 0; a.s1 = chain_plan.cend[gi]; a.deferred = gi > 0 ? 1 : 0;
+    a.nblk = chain_plan.nblk; a.rb = chain_plan.rb;
+    a.bulk = d_chain_tasks + L.bulk_off; a.nbulk = L.nbulk;
+    a.flags = d_chain_flags; a.abort_word = chain_plan.nflags - 1;
+    a.epoch = chain_epoch << kChainEpochShift;
+    a.counters = d_counters + counter_next;
+    a.trace = d_chain_trace; a.trace_cap = kChainTraceCap;
+    counter_next += 8;
+    const int avail = whole_chip ? num_cus : std::max(2, reserved_cus > 0 ? reserved_cus : 32);
+    const int grid = std::max(2, std::min(avail, 1 + L.nbulk));
+    Scope sc(this, KID_CHOL_DIAG, sc_);
+    ++launch_cnt[EKF_LAUNCH_CHAIN_PERSISTENT];
+    if constexpr (kIsF32) k_chain_persistent<<<grid, 1024, kChainLds, sc_>>>(a);
+    return EKF_OK;
+  }
+
   // Block steps [step0, step1) of the serial chain of chunk [c0, c1) on stream sc_: diagonal factor, panel (rows
   // below the block + the chunk's identity-strip rows), trailing update (strip tiles stop at c1).
   void chain_steps(int step0, int step1, int c0, int c1, int m, int m_pad, hipStream_t sc_, bool skip_panel = false) {
@@ -1444,11 +1536,15 @@ struct Filter : FilterBase {
     const bool recompute = kIsF32 && opt_mfma && opt_wrecompute && nchunks > 1 && tile == 128 && !oneblock;
     int step = 0;
     bool b_inflight = false;
+    // the chain of a chunk as ONE look-ahead launch (ekf_chain.hpp) instead of three launches per block step
+    const bool pchain = chain_persistent_ok() && nb == 128 && !oneblock && nsteps >= 2;
+    if (pchain) { rc = chain_begin_update(nsteps, nchunks, cend); if (rc) return rc; }
     for (int gi = 0; gi < nchunks; ++gi) {
       const int c0 = step * nb, c1 = cend[gi] * nb;
       // chunk 0 has the chip to itself; later chunks run beside the tile GEMMs of stream_b, on the reserved CUs
       hipStream_t sc_ = stream;
-      chain_steps(step, cend[gi], c0, c1, m, m_pad, sc_, oneblock);
+      if (pchain) { rc = chain_launch(gi, m, gi == 0, sc_); if (rc) return rc; }
+      else chain_steps(step, cend[gi], c0, c1, m, m_pad, sc_, oneblock);
       step = cend[gi];
       const int width = c1 - c0;
       // the last chunk has nothing left to overlap with: it runs on the main stream, on every CU
@@ -1786,6 +1882,15 @@ struct Filter : FilterBase {
   // which = 0: W (the columns of every chunk as the solve read them), 1: V = W L^-T; row-major rows x cols
   int peek_work(int which, void* out, int r0, int c0, int rows, int cols) override {
     HIPCHK(hipSetDevice(device));
+    if (which == 2) {
+      // the task trace of the persistent chain kernel (EKF_CHAIN_TRACE=1): `rows` records of 8 32-bit words from record
+      // r0 on (cols must be 8; record -1 = the header, word 0 = records written); the words are copied as they are
+      if (!d_chain_trace) FAIL(EKF_ERR_STATE, "no chain trace (create the filter with EKF_CHAIN_TRACE=1)");
+      if (cols != 8 || r0 < -1 || rows < 0 || r0 + rows > kChainTraceCap) FAIL(EKF_ERR_ARG, "trace block out of range");
+      HIPCHK(hipDeviceSynchronize());
+      HIPCHK(hipMemcpy(out, d_chain_trace + 8 * (size_t)(r0 + 1), (size_t)rows * 8 * sizeof(unsigned), hipMemcpyDeviceToHost));
+      return EKF_OK;
+    }
     if (which < 0 || which > 1) FAIL(EKF_ERR_ARG, "workspace id out of range");
     if (r0 < 0 || c0 < 0 || rows < 0 || cols < 0 || r0 + rows > n_pad + NB() || c0 + cols > ldy)
       FAIL(EKF_ERR_ARG, "workspace block out of range");
@@ -2908,10 +3013,13 @@ struct Filter : FilterBase {
     if constexpr (kIsF32) sh_rec = opt_mfma && opt_wrecompute && nb == 128 && nchunks > 1;
     int step = 0;
     bool side_busy = false;
+    const bool pchain = chain_persistent_ok() && nb == 128 && nsteps >= 2;
+    if (pchain) { rc = chain_begin_update(nsteps, nchunks, cend); if (rc) return rc; }
     int pend_c0 = -1, pend_c1 = -1, pend_g = -1;           // overlapped chunk whose downdate is still to be issued
     for (int gi = 0; gi < nchunks; ++gi) {
       const int c0 = step * nb, c1 = cend[gi] * nb, width = c1 - c0;
-      chain_steps(step, cend[gi], c0, c1, m, m_pad, stream);
+      if (pchain) { rc = chain_launch(gi, m, gi == 0, stream); if (rc) return rc; }
+      else chain_steps(step, cend[gi], c0, c1, m, m_pad, stream);
       step = cend[gi];
       const bool overlap = (gi + 1 < nchunks);
       hipStream_t ss = overlap ? stream_b : stream;

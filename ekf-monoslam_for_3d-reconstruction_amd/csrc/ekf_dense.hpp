@@ -1354,10 +1354,44 @@ __device__ __forceinline__ void diag_factor16(float* a, int LDA, int K0, float* 
   EKF_DIAG_STAMP(3);
 }
 
-template <int MASK = 7>
-__global__ void __launch_bounds__(1024)
-k_chol_diag_packed(float* __restrict__ Aglob, int ld, float* __restrict__ Dinv, int* __restrict__ status,
-                   int nblk_real = 8) {
+// The body is shared by the stand-alone launch (k_chol_diag_packed, plain loads and stores) and by the persistent chain
+// kernel (ekf_chain.hpp: write-through stores, L1-bypassing loads): ldA(i, j0) = A[i][j0 .. j0 + 3], stA(i, j0, v) stores
+// them, stD(i, j, x) stores Linv[i][j].  1024 lanes; the LDS arrays are the caller's.
+struct DiagLds {
+  float* a;                                      // [128 * 132]
+  float (*x16)[16 * 20];                         // [2]
+  float (*rinv)[16];                             // [2]
+  float* junk16;                                 // [64 * 16]
+};
+// Three pieces (the persistent chain kernel's critical workgroup keeps the block in LDS between them and skips the load):
+//   diag_load_lds    global -> LDS image (lower triangle, zeros above)
+//   diag_factor_lds  the factorisation inside the image: L in the lower triangle, Z = L^-T in the strict upper one
+//   diag_store_lds   L -> global, L^-1 = Z^T -> Dinv
+template <typename LdA>
+__device__ __forceinline__ void diag_load_lds(LdA ldA, float* a) {
+  constexpr int NB = 128, LDA = NB + 4, NT = 1024, NLD = NB * NB / 4 / NT;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x;
+  // 4096 float4 of the block, all loads in flight before the first LDS write
+  f4 v[NLD];
+#pragma unroll
+  for (int p = 0; p < NLD; ++p) {
+    const int q = tid + NT * p;                  // float4 index: row q / 32, columns 4 (q % 32) ..
+    v[p] = ldA(q >> 5, 4 * (q & 31));
+  }
+#pragma unroll
+  for (int p = 0; p < NLD; ++p) {
+    const int q = tid + NT * p;
+    const int i = q >> 5, j0 = 4 * (q & 31);
+    f4 w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = (j0 + e <= i) ? v[p][e] : 0.f;
+    *reinterpret_cast<f4*>(a + i * LDA + j0) = w;
+  }
+}
+
+template <int MASK>
+__device__ __forceinline__ void diag_factor_lds(int* __restrict__ status, int nblk_real, const DiagLds& L) {
   // nblk_real: 16-column blocks that hold real rows of S; the rest of the 128 block is the identity padding of
   // the last step (L = Z = I there, decoupled from the real part) and is written back untouched.
   // Round 3: SIXTEEN waves.  Measured per 16-column block (tools/diag_bench.hip, s_memtime stamps of wave 0): the factoring
@@ -1365,35 +1399,17 @@ k_chol_diag_packed(float* __restrict__ Aglob, int ld, float* __restrict__ Dinv, 
   // (a 16 x 16 tile is ~30 instructions around 4 MFMAs, and one wave issues an instruction every ~8-10 cycles): the first
   // blocks waited for the UPDATE, not for the factor.  Twelve waves share the tiles now; the waves 4, 8, 12 sit on the
   // factoring wave's SIMD and take none (they would share its issue slots and its matrix pipe).
-  constexpr int NB = 128, LDA = NB + 4, NT = 1024, NBLK = NB / 16, NLD = NB * NB / 4 / NT;
+  constexpr int NB = 128, LDA = NB + 4, NBLK = NB / 16;
   typedef float f4 __attribute__((ext_vector_type(4)));
-  __shared__ __attribute__((aligned(16))) float a[NB * LDA];
-  __shared__ __attribute__((aligned(16))) float x16[2][16 * 20];   // double-buffered: block b+1 is factored while block b's
-  __shared__ __attribute__((aligned(16))) float rinv[2][16];       // trailing update is still being applied
-  __shared__ float junk16[64 * 16];              // store target of the lanes that hold no element of an L16 column
+  float* const a = L.a;
+  float (*const x16)[16 * 20] = L.x16;           // double-buffered: block b+1 is factored while block b's
+  float (*const rinv)[16] = L.rinv;              // trailing update is still being applied
+  float* const junk16 = L.junk16;                // store target of the lanes that hold no element of an L16 column
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: tile indices and row offsets stay in SGPRs
   const int lr = lane & 15, lq = lane >> 4;
   const int helper = ((wave & 3) == 0) ? -1 : (wave >> 2) * 3 + (wave & 3) - 1;   // 0 .. 11 over the waves off SIMD 0
   __builtin_amdgcn_s_setprio(3);    // serial chain: win issue arbitration against co-resident tile-GEMM waves
-  {
-    // 4096 float4 of the block, all loads in flight before the first LDS write
-    f4 v[NLD];
-#pragma unroll
-    for (int p = 0; p < NLD; ++p) {
-      const int q = tid + NT * p;                  // float4 index: row q / 32, columns 4 (q % 32) ..
-      v[p] = *reinterpret_cast<const f4*>(Aglob + (size_t)(q >> 5) * ld + 4 * (q & 31));
-    }
-#pragma unroll
-    for (int p = 0; p < NLD; ++p) {
-      const int q = tid + NT * p;
-      const int i = q >> 5, j0 = 4 * (q & 31);
-      f4 w;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) w[e] = (j0 + e <= i) ? v[p][e] : 0.f;
-      *reinterpret_cast<f4*>(a + i * LDA + j0) = w;
-    }
-  }
   __syncthreads();
   if ((MASK & 1) && wave == 0) diag_factor16(a, LDA, 0, x16[0], rinv[0], lane, status, junk16);
   __syncthreads();
@@ -1443,6 +1459,13 @@ k_chol_diag_packed(float* __restrict__ Aglob, int ld, float* __restrict__ Dinv, 
     __syncthreads();
     EKF_KSTAMP(b, 3);
   }
+}
+
+template <typename StA, typename StD>
+__device__ __forceinline__ void diag_store_lds(StA stA, StD stD, const float* a) {
+  constexpr int NB = 128, LDA = NB + 4, NT = 1024, NLD = NB * NB / 4 / NT;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x;
   // L: row i, columns 4 jq ..: one 16-byte LDS read, one coalesced 16-byte store.  L^-1 = Z^T: row j of Z (strict upper
   // storage), columns 4 iq .. as one 16-byte LDS read, stored as Dinv[4 iq + e][j] -- the lanes of a wave walk j, so
   // each of the four stores is a coalesced 256-byte row segment (a transposed LDS read would meet 8-way conflicts).
@@ -1454,7 +1477,7 @@ k_chol_diag_packed(float* __restrict__ Aglob, int ld, float* __restrict__ Dinv, 
     f4 lo;
 #pragma unroll
     for (int e = 0; e < 4; ++e) lo[e] = (j0 + e <= i) ? l[e] : 0.f;
-    *reinterpret_cast<f4*>(Aglob + (size_t)i * ld + j0) = lo;
+    stA(i, j0, lo);
   }
 #pragma unroll
   for (int p = 0; p < NLD; ++p) {
@@ -1465,9 +1488,33 @@ k_chol_diag_packed(float* __restrict__ Aglob, int ld, float* __restrict__ Dinv, 
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int i = i0 + e;
-      Dinv[(size_t)i * NB + j] = (j < i) ? z[e] : ((j == i) ? 1.f / ljj : 0.f);   // Linv[i][j] = Z[j][i]
+      stD(i, j, (j < i) ? z[e] : ((j == i) ? 1.f / ljj : 0.f));   // Linv[i][j] = Z[j][i]
     }
   }
+}
+
+template <int MASK, typename LdA, typename StA, typename StD>
+__device__ __forceinline__ void chol_diag_packed_body(LdA ldA, StA stA, StD stD, int* __restrict__ status, int nblk_real,
+                                                      const DiagLds& L) {
+  diag_load_lds(ldA, L.a);
+  diag_factor_lds<MASK>(status, nblk_real, L);
+  diag_store_lds(stA, stD, L.a);
+}
+
+template <int MASK = 7>
+__global__ void __launch_bounds__(1024)
+k_chol_diag_packed(float* __restrict__ Aglob, int ld, float* __restrict__ Dinv, int* __restrict__ status,
+                   int nblk_real = 8) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) float a[128 * 132];
+  __shared__ __attribute__((aligned(16))) float x16[2][16 * 20];
+  __shared__ __attribute__((aligned(16))) float rinv[2][16];
+  __shared__ float junk16[64 * 16];
+  const DiagLds L{a, x16, rinv, junk16};
+  chol_diag_packed_body<MASK>(
+      [&](int i, int j0) { return *reinterpret_cast<const f4*>(Aglob + (size_t)i * ld + j0); },
+      [&](int i, int j0, const f4& v) { *reinterpret_cast<f4*>(Aglob + (size_t)i * ld + j0) = v; },
+      [&](int i, int j, float x) { Dinv[(size_t)i * 128 + j] = x; }, status, nblk_real, L);
 }
 
 // ---------------------------------------------------------------------------------------

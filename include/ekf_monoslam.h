@@ -294,7 +294,11 @@ int ekf_get_sigma_block(ekf_filter* f, void* out, int r0, int c0, int rows, int 
 int ekf_set_sigma_block(ekf_filter* f, const void* in, int r0, int c0, int rows, int cols);
 /* Diagnostics only (no reference counterpart; tools/determinism_probe_sharded.py): a block of the workspace of the LAST
  * update, row-major rows x cols in the filter's dtype.  which = 0: W = Sigma H^T as the triangular solves read it,
- * 1: V = W L^-T (the factor of the covariance downdate).  Rows: state rows, then the padding; columns: 2 x list slot. */
+ * 1: V = W L^-T (the factor of the covariance downdate).  Rows: state rows, then the padding; columns: 2 x list slot.
+ * which = 2 (round 6; a filter created with EKF_CHAIN_TRACE=1 in the environment): the task trace of the persistent chain
+ * kernel of the last update -- `rows` records of 8 32-bit words from record r0 on (cols = 8; r0 = -1 starts at the header,
+ * whose word 0 counts the records): type | workgroup << 8 | critical << 24, block step, row block, column block, and the
+ * 100 MHz wall clock at draw / dependencies met / computed / published (tools/chain_trace.py). */
 int ekf_peek_workspace(ekf_filter* f, int which, void* out, int r0, int c0, int rows, int cols);
 /* Covariance_Parameter (vR.cpp:841-866): trace of Sigma[0:7,0:7]. */
 int ekf_covariance_parameter(ekf_filter* f, double* out);

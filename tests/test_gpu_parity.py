@@ -925,7 +925,8 @@ def test_w_recompute_agrees_with_the_right_looking_w_update():
     # bf16x6 path (the default): the knobs that act on it
     ({"EKF_ROW_GEMV": "0"}, ("row_rider", "row_tile_gemm")),                            # the innovation row through the tile GEMM: same bits by design
     ({"EKF_RESERVED_CUS": "24"}, ()), ({"EKF_RESERVED_CUS": "48"}, ()),                 # another grid for every overlapped launch, the same tiles
-    ({"EKF_CHAIN_PERSISTENT": "0"}, ("chain_step_launches", "chain_persistent")),       # round 6: the look-ahead chain kernel against the per-step launches
+    ({"EKF_CHAIN_PERSISTENT": "1"}, ("chain_step_launches", "chain_persistent")),       # round 6: the look-ahead chain kernel (opt-in) against the per-step launches
+    ({"EKF_SPLIT_BF16": "0", "EKF_CHAIN_PERSISTENT": "1"}, ("chain_step_launches", "chain_persistent")),
 ])
 def test_launch_structure_knobs_are_bit_identical(monkeypatch, knobs, differs):
     """The tuning knobs of DESIGN.md section 3 change WHICH workgroup computes a tile, in which launch and in what tile
