@@ -43,12 +43,49 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
+def committed_mfma_busy(kernel_prefix):
+    """SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES-normalised duration) of the dominant kernel from the newest
+    committed counter pass (profiles/r<k>_pmc_mfma.json, tools/pmc_mfma.py) whose csrc fingerprint matches these sources."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma.json")),
+                   key=lambda f: -int(re.search(r"r(\d+)_pmc", os.path.basename(f)).group(1)))
+    for path in files:
+        try:
+            doc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if doc.get("csrc_sha16") != csrc_sha():
+            continue
+        for name, row in doc.get("kernels", {}).items():
+            if name.startswith(kernel_prefix) and "mfma_busy" in row:
+                return round(float(row["mfma_busy"]), 4), f"profiles/{os.path.basename(path)} (csrc sha {doc['csrc_sha16']})"
+    return None, f"no committed MFMA counter pass matches the kernel sources of this run (csrc sha {csrc_sha()})"
+
+
+def library_identity(pkg):
+    """Which binary ran (an EKF_LIB_PATH left over from an A/B run must not go unnoticed)."""
+    import hashlib
+    from ekf_monoslam_amd import capi
+    path = capi.LIB_PATH
+    try:
+        sha = hashlib.sha1(open(path, "rb").read()).hexdigest()[:16]
+    except OSError:
+        sha = None
+    return {"path": os.path.relpath(path, ROOT) if path.startswith(ROOT) else path, "sha16": sha,
+            "overridden_by_EKF_LIB_PATH": bool(os.environ.get("EKF_LIB_PATH")), "csrc_sha16": csrc_sha()}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--features", type=int, default=1000)
+    ap.add_argument("--device-warmup-ms", type=float, default=80.0,
+                    help="before the W warm-up steps: this many ms of the same step on a SCRATCH map (never the measured one), so that the "
+                         "clocks the device holds under this load are reached before the timed region, not inside it (a 20-step window "
+                         "behind thousands of tiny map-building launches otherwise sits in the clock ramp); 0 disables; reported in the line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-propagate-pass", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true",
@@ -60,7 +97,7 @@ def parse():
     ap.add_argument("--exact-fp32", action="store_true",
                     help="EKF_OPT_SPLIT_BF16 = 0: every contraction on v_mfma_f32_32x32x2_f32 (the round 1-4 arithmetic).  The default "
                          "(round 5) runs the covariance downdate of large maps on the bf16 matrix pipe at fp32 accuracy: each "
-                         "fp32 operand split exactly into 3 bf16, the six products above 2^-25 |a||b| accumulated in fp32")
+                         "fp32 operand split exactly into 3 bf16, six of the nine products accumulated in fp32 (dropped: <= 2^-24 |a||b|)")
     ap.add_argument("--no-secondary-exact-fp32", action="store_true",
                     help="skip the short secondary pass that times the same steps with EKF_OPT_SPLIT_BF16 = 0")
     ap.add_argument("--resize-every", type=int, default=0,
@@ -432,6 +469,27 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
     bpf = 2 * n_feat * 4
     torch.cuda.synchronize()
 
+    # device warm-up on a scratch map (see --device-warmup-ms): the measured maps are not touched, the W warm-up steps and the
+    # K timed steps follow unchanged
+    device_warmup = {"requested_ms": args.device_warmup_ms, "steps_on_scratch_map": 0, "ms": 0.0}
+    if args.device_warmup_ms > 0:
+        scratch = build_filter(pkg, cfg, n_feat, px0)
+        for k, v in opts:
+            scratch.set_option(k, v)
+        tw = time.perf_counter()
+        nw = 0
+        while (time.perf_counter() - tw) * 1e3 < args.device_warmup_ms and nw < segment_frames(n_feat):
+            f_ = nw % z.shape[0]
+            scratch.predict()
+            scratch.update_device(d_z.data_ptr() + f_ * bpf, d_idx.data_ptr(), n_feat, False)
+            nw += 1
+            if nw % 8 == 0:
+                scratch.synchronize()
+        scratch.synchronize()
+        device_warmup.update(steps_on_scratch_map=nw, ms=round((time.perf_counter() - tw) * 1e3, 2))
+        scratch.close()
+        del scratch
+
     run_steps(flt, d_z, d_idx, n_feat, 0, args.warmup, bpf)
     flt.synchronize()
     torch.cuda.synchronize()
@@ -463,7 +521,14 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
     roofline = None
     pieces = 1
     # which arithmetic the downdate ran in: the library switches to the bf16x6 kernel for maps of >= 23 tile rows
-    split_used = (not args.exact_fp32) and (-(-n // 128)) * ((-(-n // 128)) + 1) // 2 >= 256
+    # (round 6: read from the library's launch counters -- ekf_launch_count -- instead of re-deriving its selection rule)
+    launches = {}
+    for f_ in flt.filters:
+        for k_, v_ in f_.launch_counts().items():
+            launches[k_] = launches.get(k_, 0) + v_
+    split_used = launches.get("downdate_bf16x6", 0) > 0
+    if split_used and (launches.get("downdate_f32", 0) + launches.get("downdate_f32_fused_wu", 0) + launches.get("downdate_f32_half_tail", 0)) > 0:
+        raise SystemExit("bench: the downdate ran on both arithmetics in one run (a per-chunk fall-back): the line would misreport dtype / roofline")
     if syrk_cnt:
         # the timed launches and their algorithmic flop come from the library (ekf_profile_read / ekf_profile_work):
         # n^2 x the real columns of every downdate launch (symmetric half).  Exact-fp32 path with the default
@@ -512,20 +577,18 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
     chol_flop = float(m) ** 3 / 3.0 + sum(float(w) ** 3 / 3.0 for w in widths)
     step_flop = float(n) * n * m + solve_flop + wupd_flop + reval_flop + chol_flop + 26.0 * n * m + 26.0 * m * m
     ach_step = step_flop / (ms_per_step * 1e-3) / 1e12
-    roofline_step = {"bound": "mfma" if n_feat >= 600 else "latency", "achieved": round(ach_step, 2), "peak": PEAK_F32_MFMA_TF,
-                     "unit": "TFLOP/s", "frac": round(ach_step / PEAK_F32_MFMA_TF, 4), "traffic": None,
+    # (round 6: no fraction any more -- the step mixes the bf16x6 downdate, f32-MFMA solves and a latency-bound chain, and a
+    # fraction of any ONE peak says nothing; the achieved figure and the flop breakdown are kept for continuity)
+    roofline_step = {"bound": "mixed: bf16x6 downdate (matrix pipe), f32-MFMA solves, latency-bound Cholesky chain" if n_feat >= 600 else "latency",
+                     "achieved": round(ach_step, 2), "peak": None, "unit": "TFLOP/s (algorithmic fp32 flop of the whole step)",
+                     "frac": None, "traffic": None,
                      "algorithmic_flop_per_step": step_flop,
                      "flop_breakdown": {"downdate": float(n) * n * m, "solve": solve_flop, "w_update": wupd_flop,
                                         "w_reevaluation": reval_flop, "cholesky_and_chunk_inverses": chol_flop},
                      "chunk_ends_block_steps": ends, "block": block, "w_recompute": wrec,
                      "flop_of_the_round_1_3_formulation": float(n) * n * m + float(n) * m * m / 2.0 * 1.1 + chol_flop
                      + sum(2.0 * n * w * max(0, m - c1) for w, c1 in zip(widths, c1s)) + 26.0 * n * m + 26.0 * m * m,
-                     "flop_note": "a LOWER whole-step fraction than in rounds 1-3 (0.50) with a higher updates/s is fewer flop per "
-                                  "step (the W update of 15 GFLOP is gone since round 4), not a slower chip; under the default "
-                                  "EKF_OPT_SPLIT_BF16 = 1 the downdate's flop run on the bf16 pipe, so this fraction of the F32 "
-                                  "peak is a lower bound on nothing -- it is kept for continuity with rounds 1-4",
-                     "basis": "whole step: algorithmic flop of the formulation executed (the library's column chunks) / "
-                              "ms_per_step, against the f32 MFMA peak"}
+                     "basis": "whole step: algorithmic flop of the formulation executed (the library's column chunks) / ms_per_step"}
 
     # HBM traffic per launch: measured by two rocprofv3 --pmc child passes of this run (live_pmc_traffic); when those are
     # not available (child of a profiler, no rocprofv3, --no-live-traffic) from the committed PMC passes, which belong to
@@ -561,6 +624,7 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
     if roofline:
         roofline["traffic"] = pmc[dd_key]["hbm_bytes_per_launch"] if dd_key else None
         roofline["traffic_source"] = pmc_note
+        roofline["mfma_busy"], roofline["mfma_busy_source"] = committed_mfma_busy("k_syrk_bf16x6" if split_used else "k_gemm_mfma<2, false")
     result = {
         "metric": "EKF updates/sec at N features (state dim 14+6N)",
         "value": round(args.steps / elapsed, 2), "unit": "updates/s",
@@ -569,14 +633,17 @@ def bench_single(pkg, cfg, n_feat, px0, z, args, dev, torch):
         "vs_baseline": None,
         "dtype": "f32" if not split_used else
                  "f32 (state, covariance, every accumulation and every other contraction in fp32; the products of the covariance "
-                 "downdate as 3 x bf16 splits of the fp32 operands, six bf16 products per fp32 product, exact to 2^-25 |a||b| "
-                 "-- below half an ulp of the fp32 product; EKF_OPT_SPLIT_BF16 = 0 / --exact-fp32 runs v_mfma_f32_32x32x2_f32)",
+                 "downdate as 3 x bf16 splits of the fp32 operands, six bf16 products per fp32 product: the dropped terms are "
+                 "<= 2^-24 |a||b| in the worst case (2^-28 on average) -- the size of the fp32 product's own rounding; EKF_OPT_SPLIT_BF16 = 0 / --exact-fp32 runs v_mfma_f32_32x32x2_f32)",
         "data": "synthetic",
         "config": {"workload": f"N={n_feat} inverse-depth features, n={n}, M=N measured per frame, "
                                f"fp32, 1xMI355X ({ {200: 'BASELINE configs[1]', 1000: 'BASELINE configs[2]', 4000: 'BASELINE configs[4] size on one GPU'}.get(n_feat, 'custom size') })",
                    "features": n_feat, "state_dim": n, "measured_per_frame": n_feat,
                    "camera": "conf_kinect.cfg/scale2", "dT": 1.0 / 30.0,
                    "frames_per_map": flt.seg, "maps": len(flt.filters)},
+        "device_warmup": device_warmup,
+        "library": library_identity(pkg),
+        "downdate_launch_kinds": {k_: v_ for k_, v_ in launches.items() if k_.startswith(("downdate", "row_", "chain"))},
         "run_sane": sane, "features_visible_at_end": int(vis.sum()), "features_rho_nonpositive_at_end": int(rem.sum()),
         "roofline": roofline,
         "roofline_step": roofline_step,

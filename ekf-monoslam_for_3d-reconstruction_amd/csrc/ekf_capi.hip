@@ -653,8 +653,9 @@ struct Filter : FilterBase {
     for (int i = 0; i < N; ++i) { if (p) p[i] = pos[i]; if (c) c[i] = coding[i]; }
     return EKF_OK;
   }
-  void* dev_mu() override { return mu(); }
-  void* dev_sigma(int* l) override { if (l) *l = ld; return S(); }
+  // (the caller may write through these pointers: the gathered diagonal blocks of a sharded filter are stale from here on)
+  void* dev_mu() override { diag_synced = false; return mu(); }
+  void* dev_sigma(int* l) override { diag_synced = false; if (l) *l = ld; return S(); }
 
   // ---- a12 add feature --------------------------------------------------------------------
   int add_feature(double u, double v) override {

@@ -212,7 +212,7 @@ def bench(pkg, cfg, n_feat, px0, z, args, rank, world, dev):
     if dd_cnt:
         flop = work.get("downdate_syrk", 0.0) / dd_cnt
         ach = flop / (dd_ms / dd_cnt * 1e-3) / 1e12
-        split = n >= 23 * 128 - 127 and not os.environ.get("EKF_SPLIT_BF16") == "0"      # the library's own rule (23 tile rows)
+        split = flt.launch_counts().get("downdate_bf16x6", 0) > 0     # which downdate kernel the rank RAN (ekf_launch_count), not a re-derived rule
         if split:
             # k_syrk_bf16x6: six bf16 products per algorithmic fp32 product -> roofline = dense bf16 peak / 6 (bench.py)
             peak6 = 2500.0 / 6.0

@@ -92,10 +92,13 @@ enum ekf_option {
   EKF_OPT_PIPELINE = 3,
   /* 1 (default since round 5): the covariance downdate Sigma -= V_g V_g^T of large maps (at least 23 tile rows of 128: N >= ~480
    * inverse-depth features on a 256-CU device) runs on the bf16 matrix pipe AT FP32 ACCURACY: each fp32 operand is split
-   * exactly into three bf16 values, a = a1 + a2 + a3, and the six products above 2^-25 |a||b| -- below half an ulp of the
-   * fp32 product -- are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (csrc/ekf_syrk6.hpp).  Every other contraction, every
+   * exactly into three bf16 values, a = a1 + a2 + a3, and six of the nine bf16 products -- all but a2 b3, a3 b2, a3 b3, which
+   * together are <= 2^-24 |a||b| in the worst case and 2^-28 |a||b| on average, the size of the fp32 product's own rounding
+   * (2^-24 worst, 2^-25.5 mean) -- are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (csrc/ekf_syrk6.hpp).  Every other contraction, every
    * accumulation, the state and the covariance stay fp32.  Measured against the fp64 oracle the result is as close as the
-   * fp32 instruction's (tests/test_gpu_parity.py::test_split_bf16_downdate_is_fp32_accurate); it is not bit-equal
+   * fp32 instruction's (tests/test_gpu_parity.py::test_split_bf16_downdate_is_fp32_accurate runs BOTH arithmetics -- the
+   * launch counters prove which kernel each filter ran -- and ::test_n1000_exact_fp32_downdate_matches_fp64_oracle /
+   * ::test_n1000_default_pipeline_matches_fp64_oracle hold each at N = 1000 against the fp32-oracle yardstick); it is not bit-equal
    * to it.  Sigma stays exactly symmetric, and a rank of a sharded filter computes bit-identical rows (every element pair is
    * one sum, whoever computes it).  0: every contraction on v_mfma_f32_32x32x2_f32 (the arithmetic of rounds 1-4).  fp32
    * filters only; smaller maps and fp64 filters are not affected. */
@@ -117,8 +120,9 @@ enum ekf_option {
    * W'_h = (Sigma - sum_{g<h} V_g V_g^T) H_h^T, algebraically what the right-looking GEMM update
    * W_h -= V_g L_hg^T produces, for 26 n w_h flop and one read of those columns of Sigma instead of 2 n w_g w_h flop
    * (15 of the 99 GFLOP of a step at N = M = 1000; 15 % at N = 4000); only the innovation row is still updated
-   * right-looking (inside the downdate launch).  0: the right-looking W update of rounds 1-3 (the sharded step keeps
-   * it: there the W update of a rank runs beside the gather of V_g).  Same result up to fp32 rounding. */
+   * right-looking (inside the downdate launch).  0: the right-looking W update of rounds 1-3.  The sharded step runs the
+   * same sequential form since round 5 (a rank re-evaluates ITS rows of W from its downdated rows of Sigma).  Same result
+   * up to fp32 rounding. */
   EKF_OPT_W_RECOMPUTE = 7
 };
 
@@ -392,9 +396,12 @@ int ekf_launch_count(ekf_filter* f, int kind, long long* launches);
  *   update    nu; W = Sigma H^T rows {camera, own}; rows of S of the own MEASURED features
  *       -> all-gather of the row panels of S                                           "reassemble S"
  *             Cholesky chain of S in column chunks (replicated); per chunk g, beside the chain on a second stream:
- *             V_g = W_g Z_gg and the right-looking W update for rows {camera tile, own panel}
+ *             V_g = W_g Z_gg for rows {camera tile, own panel, innovation row} (one queued launch)
  *       -> all-gather of the own rows of V_g                                           (n x 2M scalars per step in all)
- *             Sigma[own rows, :] -= V_g[own rows] V_g^T (+ the replicated camera tile); then mu += V y, normalisation.
+ *             Sigma[own rows, :] -= V_g[own rows] V_g^T (+ the replicated camera tile; the canonical tiles of k_syrk_bf16x6 that
+ *             touch an own block: bit-identical rows), then W' of the next chunk re-evaluated on rows {camera, own} from the
+ *             downdated Sigma (round 5: the sequential form; the right-looking W update of rounds 1-4 only under
+ *             EKF_OPT_W_RECOMPUTE = 0); after the last chunk mu += V y, normalisation.
  * Any measured subset (strictly ascending list, M <= N), inverse-depth and XYZ features, the plane rows and any N
  * (ranks may own different numbers of features, or none) are supported.  add_feature appends to the LAST rank's
  * range, remove / convert compact every rank's copy alike; when a rank owns more than 1.125 x the mean number of

@@ -3,6 +3,8 @@ test-only oracle on the import path."""
 import os
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
@@ -11,6 +13,11 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # an A/B build left in the environment would make every test (and every measured parity bound) run against another
+    # binary than the committed sources: the suite refuses to start
+    if os.environ.get("EKF_LIB_PATH"):
+        raise pytest.UsageError("EKF_LIB_PATH is set (" + os.environ["EKF_LIB_PATH"] + "): the test suite only runs against the in-tree "
+                                "library built from the committed sources; unset it")
 
 
 def pytest_sessionfinish(session, exitstatus):
