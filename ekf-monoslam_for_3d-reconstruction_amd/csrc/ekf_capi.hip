@@ -62,7 +62,8 @@ static const char* kKernelNames[KID_COUNT] = {
 static const char* kLaunchNames[EKF_LAUNCH_KINDS] = {
     "downdate_bf16x6", "downdate_f32", "downdate_f32_fused_wu", "downdate_f32_half_tail", "downdate_f32_t64",
     "row_rider", "row_gemv", "row_tile_gemm", "w_update_gemm", "w_recompute",
-    "chain_step_launches", "chain_persistent", "solve", "solve_two_groups", "update_oneblock", "update_allinone"};
+    "chain_step_launches", "chain_persistent", "solve", "solve_two_groups", "update_oneblock", "update_allinone",
+    "chain_trail_diag"};
 
 static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
@@ -223,6 +224,16 @@ struct Filter : FilterBase {
   float* d_score = nullptr;
   int* d_keep = nullptr;
   int opt_panel_direct = 1;                             // EKF_PANEL_DIRECT=0: panel through the general tile GEMM
+  // the trailing update of step j and the diagonal factor of step j + 1 as ONE launch (k_trail_diag, ekf_chain.hpp);
+  // EKF_CHAIN_FUSED_DIAG=0: diag -> panel -> trailing, three launches per block step (rounds 1-5; A/B and bit-identity check)
+  int opt_chain_fused_diag = 1;
+  int opt_chain_defer = 1;                              // EKF_CHAIN_DEFER=0: a chunk's event behind the trailing update of its last step (rounds 1-5)
+  int td_min_blocks = 24;                               // EKF_TD_MIN_BLOCKS: steps with fewer blocks in their update keep the three launches
+  int* d_td_blocks = nullptr;
+  std::vector<int> td_off, td_cnt;                      // per block step: its list of (I, K) blocks inside d_td_blocks
+  int td_nblk = 0, td_nchunks = 0, td_cend[8] = {};
+  int chain_diag_ahead = -1;                            // block step whose diagonal factor the last k_trail_diag launch has already done
+  int opt_syrk_stag_half = 0, opt_syrk_stag_mod4 = 0;   // EKF_SYRK_STAGGER="h,m": de-phasing of the bf16x6 downdate's workgroups (Syrk6Args)
   // EKF_CHAIN_PERSISTENT=1: the chain as one look-ahead launch per column chunk (ekf_chain.hpp).  Bit-identical to the
   // per-step launches and NOT faster (round 6, measured: profiles/r6_chain_persistent_trace.txt): 45-50 us per block
   // step against 35-39 -- the critical workgroup moves ~360 KB per step through ONE CU, whose write-through stores run at
@@ -282,7 +293,7 @@ struct Filter : FilterBase {
                     d_status, d_tmp, d_K, d_tilemap, d_counters, d_ibuf, d_rmask, d_pts, d_tab,
                     d_frame, d_patch[0], d_patch[1], d_mpatch[0], d_mpatch[1], d_hb, d_zm, d_found, d_score, d_keep,
                     d_Vimg, d_stage_send, d_stage_recv, d_archive, d_arch_idx, d_panel_tiles, d_shard_solve, d_shard_syrk,
-                    d_chain_tasks, d_chain_flags, d_chain_trace};
+                    d_chain_tasks, d_chain_flags, d_chain_trace, d_td_blocks};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int s = 0; s < kInSlots; ++s) { if (h_in[s]) hipHostFree(h_in[s]); if (ev_in[s]) hipEventDestroy(ev_in[s]); }
     if (h_pred) hipHostFree(h_pred);
@@ -434,7 +445,14 @@ struct Filter : FilterBase {
       if (const char* e = getenv("EKF_SOLVE_S2")) opt_solve_s2 = atoi(e);
       if (const char* e = getenv("EKF_FUSED_LAUNCHES")) opt_fused = atoi(e) ? 1 : 0;   // = EKF_OPT_FUSED_LAUNCHES, for A/B runs
       if (const char* e = getenv("EKF_PANEL_DIRECT")) opt_panel_direct = atoi(e);
+      if (const char* e = getenv("EKF_SYRK_STAGGER")) {
+        opt_syrk_stag_half = atoi(e);
+        if (const char* c = strchr(e, ',')) opt_syrk_stag_mod4 = atoi(c + 1);
+      }
       if (const char* e = getenv("EKF_CHAIN_PERSISTENT")) opt_chain_persistent = atoi(e) ? 1 : 0;
+      if (const char* e = getenv("EKF_CHAIN_FUSED_DIAG")) opt_chain_fused_diag = atoi(e) ? 1 : 0;
+      if (const char* e = getenv("EKF_CHAIN_DEFER")) opt_chain_defer = atoi(e) ? 1 : 0;
+      if (const char* e = getenv("EKF_TD_MIN_BLOCKS")) td_min_blocks = std::max(1, atoi(e));
       if (const char* e = getenv("EKF_CHAIN_TRACE")) {
         if (atoi(e)) HIPCHK(hipMalloc(&d_chain_trace, (size_t)(8 + 8 * kChainTraceCap) * sizeof(unsigned)));
       }
@@ -468,9 +486,12 @@ struct Filter : FilterBase {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_diag<T, 64>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, diag_lds(64)));
     // (f32, NB = 128 uses k_chol_diag_packed: 66 KiB of static LDS)
-    if constexpr (kIsF32)
+    if constexpr (kIsF32) {
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_persistent),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLds));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trail_diag),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLds));
+    }
     return EKF_OK;
   }
   static int diag_lds(int nb) { return 2 * nb * (nb + 1) * (int)sizeof(T); }
@@ -1404,16 +1425,96 @@ struct Filter : FilterBase {
     return EKF_OK;
   }
 
+  // ---- trailing update of step j + diagonal factor of step j + 1 as one launch (k_trail_diag) ---------------------------
+  bool trail_diag_ok() const {
+    return kIsF32 && opt_mfma && opt_chain_fused_diag && (size_t)2 * ldy * ldy * sizeof(T) < ((size_t)1 << 31);
+  }
+  // per block step j of the chunk plan: the 128 x 128 blocks of its trailing update except (j + 1, j + 1) -- the S blocks
+  // (I >= K > j) and the strip blocks of the step's chunk (row blocks nblk + t, t <= j - s0, columns K in (j, s1))
+  int ensure_trail_diag_lists(int nblk, int nchunks, const int* cend) {
+    bool same = td_nblk == nblk && td_nchunks == nchunks;
+    for (int g = 0; same && g < nchunks; ++g) same = td_cend[g] == cend[g];
+    if (same) return EKF_OK;
+    std::vector<int> all;
+    td_off.assign(nblk, 0);
+    td_cnt.assign(nblk, 0);
+    for (int g = 0; g < nchunks; ++g) {
+      const int s0 = g ? cend[g - 1] : 0, s1 = cend[g];
+      for (int j = s0; j < s1; ++j) {
+        td_off[j] = (int)all.size();
+        for (int K = j + 1; K < nblk; ++K) {
+          for (int I = K; I < nblk; ++I) {
+            if (I == j + 1) continue;                                   // (j + 1, j + 1): workgroup 0's
+            all.push_back(I); all.push_back(K);
+          }
+          if (K < s1)
+            for (int t = 0; t <= j - s0; ++t) { all.push_back(nblk + t); all.push_back(K); }
+        }
+        td_cnt[j] = ((int)all.size() - td_off[j]) / 2;
+      }
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    if (stream_b) HIPCHK(hipStreamSynchronize(stream_b));
+    if (d_td_blocks) HIPCHK(hipFree(d_td_blocks));
+    d_td_blocks = nullptr;
+    HIPCHK(hipMalloc(&d_td_blocks, std::max<size_t>(all.size(), 2) * sizeof(int)));
+    if (!all.empty()) HIPCHK(hipMemcpy(d_td_blocks, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice));
+    td_nblk = nblk; td_nchunks = nchunks;
+    for (int g = 0; g < nchunks; ++g) td_cend[g] = cend[g];
+    return EKF_OK;
+  }
+  // true: launched (and the factor of step + 1 is done); false: this step keeps the separate launches
+  bool launch_trail_diag(int step, int m, hipStream_t sc_) {
+    if constexpr (kIsF32) {
+      if (!trail_diag_ok() || NB() != 128 || td_nblk == 0 || step + 1 >= td_nblk || td_cnt[step] < td_min_blocks)
+        return false;
+      TrailDiagArgs a{};
+      a.Y = d_Y; a.ldy = ldy; a.y_bytes = (unsigned)((size_t)2 * ldy * ldy * sizeof(T));
+      a.Dinv = d_Dinv; a.dinv_bytes = (unsigned)((size_t)(ldy / 64) * 128 * 128 * sizeof(T));
+      a.status = d_status; a.m = m; a.j = step;
+      a.blocks = d_td_blocks + td_off[step]; a.nblocks = td_cnt[step]; a.do_diag = 1;
+      Scope sc(this, KID_CHOL_TRAILING, sc_);
+      ++launch_cnt[EKF_LAUNCH_CHAIN_TRAIL_DIAG];
+      k_trail_diag<<<a.nblocks + 1, 1024, kChainLds, sc_>>>(a);
+      chain_diag_ahead = step + 1;
+      return true;
+    }
+    return false;
+  }
+
   // Block steps [step0, step1) of the serial chain of chunk [c0, c1) on stream sc_: diagonal factor, panel (rows
   // below the block + the chunk's identity-strip rows), trailing update (strip tiles stop at c1).
-  void chain_steps(int step0, int step1, int c0, int c1, int m, int m_pad, hipStream_t sc_, bool skip_panel = false) {
+  // `defer_last`: the trailing update of the chunk's LAST step is left to the next call (it only touches columns >= c1, so
+  // the chunk -- its columns of L and its strip -- is complete without it, and the caller records the chunk's event one
+  // launch earlier: the second stream starts on the chunk while this update is still running)
+  struct PendingTrailing { int step = -1, c0 = 0, c1 = 0; } chain_pending;
+  void chain_trailing(int step, int c0, int c1, int m, int m_pad, hipStream_t sc_, bool allow_fused) {
     const int nb = NB();
     T* Y = d_Y;
+    const int j = step * nb, r0 = j + nb;
+    const int vrows = m_pad - c0, tcols = m_pad - r0;
+    if (r0 >= m_pad || tcols <= 0) return;
+    if (allow_fused && launch_trail_diag(step, m, sc_)) return;       // the update of this step and the factor of the next one as one launch
+    Scope sc(this, KID_CHOL_TRAILING, sc_);                            // Y[r0.., r0:] -= P P_S^T; strip rows stop at c1
+    const T* P = Y + (size_t)r0 * ldy + j;
+    T* C = Y + (size_t)r0 * ldy + r0;
+    ++launch_cnt[EKF_LAUNCH_CHAIN_STEP];
+    gemm<ROLE_TRAILING, false, 64, 64>(P, ldy, P, ldy, C, ldy, vrows, tcols, nb, T(-1), T(1), 1, r0, r0, 0, 0,
+                                       sc_, nullptr, 0, m_pad, c1);
+  }
+  void chain_steps(int step0, int step1, int c0, int c1, int m, int m_pad, hipStream_t sc_, bool skip_panel = false,
+                   bool defer_last = false) {
+    const int nb = NB();
+    T* Y = d_Y;
+    if (chain_pending.step >= 0) {
+      chain_trailing(chain_pending.step, chain_pending.c0, chain_pending.c1, m, m_pad, sc_, true);
+      chain_pending.step = -1;
+    }
     for (int step = step0; step < step1; ++step) {
       const int j = step * nb;
       T* Ajj = Y + (size_t)j * ldy + j;
       T* Dj = d_Dinv + (size_t)step * nb * nb;
-      {
+      if (chain_diag_ahead != step) {
         Scope sc(this, KID_CHOL_DIAG, sc_);
         ++launch_cnt[EKF_LAUNCH_CHAIN_STEP];
         if (nb == 128) {
@@ -1440,14 +1541,10 @@ struct Filter : FilterBase {
         ++launch_cnt[EKF_LAUNCH_CHAIN_STEP];
         launch_panel(P, Dj, vrows, sc_);
       }
-      const int tcols = m_pad - r0;
-      if (r0 < m_pad && tcols > 0) {
-        Scope sc(this, KID_CHOL_TRAILING, sc_);              // Y[r0.., r0:] -= P P_S^T; strip rows stop at c1
-        const T* P = Y + (size_t)r0 * ldy + j;
-        T* C = Y + (size_t)r0 * ldy + r0;
-        ++launch_cnt[EKF_LAUNCH_CHAIN_STEP];
-        gemm<ROLE_TRAILING, false, 64, 64>(P, ldy, P, ldy, C, ldy, vrows, tcols, nb, T(-1), T(1), 1, r0, r0, 0, 0,
-                                           sc_, nullptr, 0, m_pad, c1);
+      if (defer_last && step == step1 - 1 && r0 < m_pad) {
+        chain_pending.step = step; chain_pending.c0 = c0; chain_pending.c1 = c1;
+      } else {
+        chain_trailing(step, c0, c1, m, m_pad, sc_, !skip_panel);
       }
     }
   }
@@ -1540,12 +1637,16 @@ struct Filter : FilterBase {
     // the chain of a chunk as ONE look-ahead launch (ekf_chain.hpp) instead of three launches per block step
     const bool pchain = chain_persistent_ok() && nb == 128 && !oneblock && nsteps >= 2;
     if (pchain) { rc = chain_begin_update(nsteps, nchunks, cend); if (rc) return rc; }
+    chain_diag_ahead = -1;
+    chain_pending.step = -1;
+    td_nblk = (td_nblk == nsteps) ? td_nblk : 0;
+    if (!pchain && !oneblock && trail_diag_ok() && nb == 128 && nsteps >= 2) { rc = ensure_trail_diag_lists(nsteps, nchunks, cend); if (rc) return rc; }
     for (int gi = 0; gi < nchunks; ++gi) {
       const int c0 = step * nb, c1 = cend[gi] * nb;
       // chunk 0 has the chip to itself; later chunks run beside the tile GEMMs of stream_b, on the reserved CUs
       hipStream_t sc_ = stream;
       if (pchain) { rc = chain_launch(gi, m, gi == 0, sc_); if (rc) return rc; }
-      else chain_steps(step, cend[gi], c0, c1, m, m_pad, sc_, oneblock);
+      else chain_steps(step, cend[gi], c0, c1, m, m_pad, sc_, oneblock, opt_chain_defer && gi + 1 < nchunks);
       step = cend[gi];
       const int width = c1 - c0;
       // the last chunk has nothing left to overlap with: it runs on the main stream, on every CU
@@ -1675,6 +1776,7 @@ struct Filter : FilterBase {
           if (sc.on) prof_work[KID_DOWNDATE] += double(n) * n * (std::min(c1, m) - std::min(c0, m));
           Syrk6Args a{d_Vimg, ldy / 16, c0 / 16, width / 16, S(), ld, d_tilemap + tri6_off, tri_count, d_counters + counter_next,
                       0, 0, INT_MAX};
+          a.stag_half = opt_syrk_stag_half; a.stag_mod4 = opt_syrk_stag_mod4;
           if (row_rider) {
             a.ry = d_V + (size_t)npad_live * ldy + c0; a.rL = Y + (size_t)c1 * ldy + c0; a.rldl = ldy;
             a.rnu = d_W + (size_t)npad_live * ldy + c1; a.rcols = m_pad - c1; a.rK = width; a.nrider = (m_pad - c1 + 255) / 256;
@@ -3016,11 +3118,15 @@ struct Filter : FilterBase {
     bool side_busy = false;
     const bool pchain = chain_persistent_ok() && nb == 128 && nsteps >= 2;
     if (pchain) { rc = chain_begin_update(nsteps, nchunks, cend); if (rc) return rc; }
+    chain_diag_ahead = -1;
+    chain_pending.step = -1;
+    td_nblk = (td_nblk == nsteps) ? td_nblk : 0;
+    if (!pchain && trail_diag_ok() && nb == 128 && nsteps >= 2) { rc = ensure_trail_diag_lists(nsteps, nchunks, cend); if (rc) return rc; }
     int pend_c0 = -1, pend_c1 = -1, pend_g = -1;           // overlapped chunk whose downdate is still to be issued
     for (int gi = 0; gi < nchunks; ++gi) {
       const int c0 = step * nb, c1 = cend[gi] * nb, width = c1 - c0;
       if (pchain) { rc = chain_launch(gi, m, gi == 0, stream); if (rc) return rc; }
-      else chain_steps(step, cend[gi], c0, c1, m, m_pad, stream);
+      else chain_steps(step, cend[gi], c0, c1, m, m_pad, stream, false, opt_chain_defer && gi + 1 < nchunks);
       step = cend[gi];
       const bool overlap = (gi + 1 < nchunks);
       hipStream_t ss = overlap ? stream_b : stream;

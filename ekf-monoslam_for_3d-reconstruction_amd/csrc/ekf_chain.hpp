@@ -67,17 +67,22 @@ typedef __attribute__((address_space(1))) unsigned gu32;       // every shared w
 typedef __attribute__((address_space(1))) const int gci32;
 
 // agent-coherent accesses: aux = 16 is sc1 (loads: served by L2, never by this CU's L1; stores: write-through)
+// (AUX = 0: ordinary accesses, for the kernels whose hand-overs are launch boundaries)
+template <int AUX = 16>
 __device__ __forceinline__ f4 ld16(rsrc_t r, unsigned byte_off) {
-  return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16));
+  return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, AUX));
 }
+template <int AUX = 16>
 __device__ __forceinline__ void st16(rsrc_t r, unsigned byte_off, const f4& v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, (int)byte_off, 0, 16);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, (int)byte_off, 0, AUX);
 }
+template <int AUX = 16>
 __device__ __forceinline__ float ld4(rsrc_t r, unsigned byte_off) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 16));
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, AUX));
 }
+template <int AUX = 16>
 __device__ __forceinline__ void st4(rsrc_t r, unsigned byte_off, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)byte_off, 0, 16);
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)byte_off, 0, AUX);
 }
 
 // One lane: wait until flags[idx] >= want (same epoch, value reached), the abort word is raised or the bound is hit.
@@ -104,6 +109,7 @@ __device__ __forceinline__ bool wait_flag(gu32* flags, int abort_word, int* stat
 // (row ^ q), one barrier per K step, fragment ping-pong; lane half h of MFMA e of group s multiplies k = 8 s + 4 h + e;
 // accumulators from zero, C enters once in the epilogue: C' = fma(-1, acc, C)).  On a diagonal block the tile (0, 1)
 // is not computed (the per-step launch skips tiles above the diagonal too).
+template <int AUX = 16>
 __device__ __attribute__((noinline)) void trail(rsrc_t ry, unsigned ldy, int j, int I, int K, int only, f32x4* lds_all, int tid,
                                                 int lane, int wave) {
   constexpr int NQ = 8, TS = 64, STAGE = NQ * (TS + TS), BK = 32, NG = BK / 8;
@@ -132,7 +138,7 @@ __device__ __attribute__((noinline)) void trail(rsrc_t ry, unsigned ldy, int j, 
   f4 ra[2], rb[2];
   auto load_tile = [&](int k0) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) { ra[p] = ld16(ry, aoff[p] + 4u * k0); rb[p] = ld16(ry, boff[p] + 4u * k0); }
+    for (int p = 0; p < 2; ++p) { ra[p] = ld16<AUX>(ry, aoff[p] + 4u * k0); rb[p] = ld16<AUX>(ry, boff[p] + 4u * k0); }
   };
   auto store_tile = [&](int stage) {
     f32x4* As = lds + stage * STAGE;
@@ -182,11 +188,11 @@ __device__ __attribute__((noinline)) void trail(rsrc_t ry, unsigned ldy, int j, 
   const unsigned rbase = (unsigned)(arow0 + wr * 32 + 4 * h);
   float v[16];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) v[e] = 1.f * ld4(ry, ((rbase + (e & 3) + 8 * (e >> 2)) * ldy + c) * 4u);
+  for (int e = 0; e < 16; ++e) v[e] = 1.f * ld4<AUX>(ry, ((rbase + (e & 3) + 8 * (e >> 2)) * ldy + c) * 4u);
 #pragma unroll
   for (int e = 0; e < 16; ++e) v[e] = __builtin_fmaf(-1.f, acc[e], v[e]);
 #pragma unroll
-  for (int e = 0; e < 16; ++e) st4(ry, ((rbase + (e & 3) + 8 * (e >> 2)) * ldy + c) * 4u, v[e]);
+  for (int e = 0; e < 16; ++e) st4<AUX>(ry, ((rbase + (e & 3) + 8 * (e >> 2)) * ldy + c) * 4u, v[e]);
 }
 
 // ---- P(j; I): rows of block I of column block j  <-  P Linv_jj^T, in place -------------------------------------
@@ -307,13 +313,14 @@ __device__ __forceinline__ void crit_poll2(const CritEnv& c, int* ctl, int i0, u
 }
 // T(.; blk, blk): the lower 32 x 32 blocks, wave w < 10 = block (bi, bj); both operands from the image of the panel rows,
 // C in `cv` (requested earlier with crit_load_c); the result goes into the diagonal block's LDS image, zeros above the diagonal
+template <int AUX = 16>
 __device__ __forceinline__ void crit_load_c(rsrc_t ry, unsigned ldy, int blk, int wave, int lane, float (&cv)[16]) {
   const int h = lane >> 5, l31 = lane & 31;
   const int bi = wave >= 6 ? 3 : (wave >= 3 ? 2 : (wave >= 1 ? 1 : 0)), bj = wave - bi * (bi + 1) / 2;
   if (wave < 10) {
     const unsigned c = (unsigned)(blk * 128 + 32 * bj + l31), r0 = (unsigned)(blk * 128 + 32 * bi + 4 * h);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) cv[e] = ld4(ry, ((r0 + (e & 3) + 8 * (e >> 2)) * ldy + c) * 4u);
+    for (int e = 0; e < 16; ++e) cv[e] = ld4<AUX>(ry, ((r0 + (e & 3) + 8 * (e >> 2)) * ldy + c) * 4u);
   }
 }
 __device__ __forceinline__ void crit_trail_diag(const f32x4* pimg, float* a, int wave, int lane, const float (&cv)[16]) {
@@ -601,6 +608,70 @@ __global__ void __launch_bounds__(1024) k_chain_persistent(ChainArgs g) {
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Trailing update of block step j AND the diagonal factor of step j + 1 as ONE launch (round 6; the default chain): the
+// per-step sequence was diag(j) -> panel(j) -> trailing(j) -> diag(j + 1) ..., three launches of which the factor -- one
+// workgroup, 17 us -- had the chip to itself.  Here workgroup 0 first applies step j's update to the diagonal block
+// (j + 1, j + 1) ITSELF -- its operands, the rows of P(j; j + 1), are final before the launch: no hand-over inside it --
+// straight into the factor's LDS image, factors it and writes L_(j+1) and Dinv_(j+1), while every other workgroup takes one
+// 128 x 128 block of the trailing update (four 64 x 64 tiles of k_gemm_mfma<TRAILING>'s arithmetic).  Same sums, same
+// bits (chain::trail, chain::crit_trail_diag: the pieces of the persistent kernel above, with ordinary loads and stores:
+// the hand-overs are launch boundaries).  A step costs panel + max(update + factor, trailing) instead of their sum.
+// ---------------------------------------------------------------------------------------------------------------------
+struct TrailDiagArgs {
+  float* Y; int ldy; unsigned y_bytes;
+  float* Dinv; unsigned dinv_bytes;
+  int* status;
+  int m;                                         // real rows of S
+  int j;                                         // the step whose trailing update this is
+  const int* blocks; int nblocks;                // (I, K) pairs: the blocks of the update EXCEPT (j + 1, j + 1)
+  int do_diag;                                   // 1: workgroup 0 = block (j + 1, j + 1) + the factor of step j + 1
+};
+
+__global__ void __launch_bounds__(1024) k_trail_diag(TrailDiagArgs g) {
+  using namespace chain;
+  extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(g.Y, 0, (int)g.y_bytes, 0x27000);
+  const unsigned ldy = (unsigned)g.ldy;
+  __builtin_amdgcn_s_setprio(2);
+  if (g.do_diag && blockIdx.x == 0) {
+    const int j = g.j, blk = g.j + 1;
+    float* a = reinterpret_cast<float*>(chain_smem);
+    f32x4* pimg = reinterpret_cast<f32x4*>(chain_smem + kChainPimg);
+    // the rows of P(j; j + 1) -> the operand image (slot = kq 128 + (row ^ (kq & 7)), kq = k / 4); C = block (blk, blk)
+    f4 v[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int idx = tid + 1024 * p, row = idx >> 5, kq = idx & 31;
+      v[p] = ld16<0>(ry, (((unsigned)(blk * 128 + row)) * ldy + (unsigned)(j * 128 + 4 * kq)) * 4u);
+    }
+    float cv[16];
+    crit_load_c<0>(ry, ldy, blk, wave, lane, cv);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int idx = tid + 1024 * p, row = idx >> 5, kq = idx & 31;
+      pimg[kq * 128 + (row ^ (kq & 7))] = v[p];
+    }
+    __syncthreads();
+    crit_trail_diag(pimg, a, wave, lane, cv);
+    const DiagLds L{a, reinterpret_cast<float(*)[16 * 20]>(a + 128 * 132),
+                    reinterpret_cast<float(*)[16]>(a + 128 * 132 + 2 * 16 * 20), a + 128 * 132 + 2 * 16 * 20 + 2 * 16};
+    diag_factor_lds<7>(g.status, max(1, min(8, (g.m - blk * 128 + 15) / 16)), L);      // (starts with a barrier)
+    float* Ab = g.Y + (size_t)blk * 128 * g.ldy + (size_t)blk * 128;
+    float* Db = g.Dinv + (size_t)blk * 128 * 128;
+    const int ld_ = g.ldy;
+    diag_store_lds([&](int i, int j0, const f4& x) { *reinterpret_cast<f4*>(Ab + (size_t)i * ld_ + j0) = x; },
+                   [&](int i, int jj, float x) { Db[(size_t)i * 128 + jj] = x; }, a);
+    return;
+  }
+  const int t = (int)blockIdx.x - g.do_diag;
+  if (t >= g.nblocks) return;
+  const int I = g.blocks[2 * t], K = g.blocks[2 * t + 1];
+  trail<0>(ry, ldy, g.j, I, K, -1, reinterpret_cast<f32x4*>(chain_smem), tid, lane, wave);
 }
 
 // ---- host: the task lists of every launch of a chunk plan -------------------------------------------------------

@@ -86,6 +86,11 @@ struct Syrk6Args {
   // runs; here it runs beside 100+ us of tiles on <= 7 of the 448+ workgroup slots (round 5 first had it in k_split_image,
   // in FRONT of the downdate: 7 -> 17 us on the second stream's critical path, three times per step).
   const float* ry = nullptr; const float* rL = nullptr; int rldl = 0; float* rnu = nullptr; int rcols = 0, rK = 0, nrider = 0;
+  // De-phasing (round 6): every tile of a launch has the same K, so workgroups that start together reach their epilogues
+  // together -- 448 x 192 KB of C traffic inside a few microseconds, with the matrix pipes idle meanwhile.  The second
+  // workgroup of a CU (the second half of the grid) starts stag_half x 0.85 us late, and workgroup b another (b & 3) x
+  // stag_mod4 x 0.85 us: the two workgroups of a CU alternate between K loop and epilogue, and the C traffic of the chip is spread.
+  int stag_half = 0, stag_mod4 = 0;
 };
 
 // Every element pair {r, c}, r >= c, is computed ONCE, as element (r, c) of its canonical tile (A block = the block of r,
@@ -146,6 +151,11 @@ __global__ void __launch_bounds__(256, 2) k_syrk_bf16x6(Syrk6Args g) {
     return;
   }
   // ---- first tile -----------------------------------------------------------------------------------------------------
+  if (g.stag_half | g.stag_mod4) {
+    const int b = (int)blockIdx.x - g.nrider, nb = (int)gridDim.x - g.nrider;
+    const int units = (b >= nb / 2 ? g.stag_half : 0) + (b & 3) * g.stag_mod4;
+    for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(32);
+  }
   if (tid == 0) {
     const int t = atomicAdd(g.counter, 1);
     s_next[0] = t < g.ntiles ? g.tile_map[2 * t] : -1;

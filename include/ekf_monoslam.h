@@ -381,6 +381,7 @@ enum ekf_launch_kind {
   EKF_LAUNCH_SOLVE_TWO_GROUPS,        /* ... on two wave groups per tile (EKF_SOLVE_S2)                                  */
   EKF_LAUNCH_UPDATE_ONEBLOCK,         /* k_solve_state_oneblock (2 M + 3 <= 128)                                         */
   EKF_LAUNCH_UPDATE_ALLINONE,         /* k_update_oneblock_small (... and a small map)                                   */
+  EKF_LAUNCH_CHAIN_TRAIL_DIAG,        /* k_trail_diag: the trailing update of a block step and the factor of the next as one launch (round 6) */
   EKF_LAUNCH_KINDS
 };
 int ekf_launch_kinds(void);
