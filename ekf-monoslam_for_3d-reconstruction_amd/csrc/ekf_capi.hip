@@ -63,7 +63,7 @@ static const char* kLaunchNames[EKF_LAUNCH_KINDS] = {
     "downdate_bf16x6", "downdate_f32", "downdate_f32_fused_wu", "downdate_f32_half_tail", "downdate_f32_t64",
     "row_rider", "row_gemv", "row_tile_gemm", "w_update_gemm", "w_recompute",
     "chain_step_launches", "chain_persistent", "solve", "solve_two_groups", "update_oneblock", "update_allinone",
-    "chain_trail_diag"};
+    "chain_trail_diag", "split_image"};
 
 static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
@@ -227,6 +227,8 @@ struct Filter : FilterBase {
   // the trailing update of step j and the diagonal factor of step j + 1 as ONE launch (k_trail_diag, ekf_chain.hpp);
   // EKF_CHAIN_FUSED_DIAG=0: diag -> panel -> trailing, three launches per block step (rounds 1-5; A/B and bit-identity check)
   int opt_chain_fused_diag = 1;
+  int opt_fuse_split = 1;                               // EKF_FUSE_SPLIT=0: the plane image of V_g by its own launch behind the solve (rounds 5)
+  bool vimg_done = false;                               // this chunk's solve has written the plane image of V_g
   int opt_chain_defer = 1;                              // EKF_CHAIN_DEFER=0: a chunk's event behind the trailing update of its last step (rounds 1-5)
   int td_min_blocks = 24;                               // EKF_TD_MIN_BLOCKS: steps with fewer blocks in their update keep the three launches
   int* d_td_blocks = nullptr;
@@ -451,6 +453,7 @@ struct Filter : FilterBase {
       }
       if (const char* e = getenv("EKF_CHAIN_PERSISTENT")) opt_chain_persistent = atoi(e) ? 1 : 0;
       if (const char* e = getenv("EKF_CHAIN_FUSED_DIAG")) opt_chain_fused_diag = atoi(e) ? 1 : 0;
+      if (const char* e = getenv("EKF_FUSE_SPLIT")) opt_fuse_split = atoi(e) ? 1 : 0;
       if (const char* e = getenv("EKF_CHAIN_DEFER")) opt_chain_defer = atoi(e) ? 1 : 0;
       if (const char* e = getenv("EKF_TD_MIN_BLOCKS")) td_min_blocks = std::max(1, atoi(e));
       if (const char* e = getenv("EKF_CHAIN_TRACE")) {
@@ -1121,9 +1124,11 @@ struct Filter : FilterBase {
   template <int ROLE, bool BT, int TM = 128, int TN = 128>
   void gemm(const T* A, int lda, const T* B, int ldb, T* C, int ldc, int rows, int cols, int K, T alpha, T beta,
             int tri, int row_off, int col_off, int ktri, int ktile_off = 0, hipStream_t st = nullptr,
-            const int* tile_list = nullptr, int ntiles = 0, int zrow = 0, int zcol_end = 0) {
+            const int* tile_list = nullptr, int ntiles = 0, int zrow = 0, int zcol_end = 0, void* img = nullptr,
+            int img_nkc = 0, int img_c0 = 0) {
     GemmArgs g{A, lda, B, ldb, C, ldc, K, double(alpha), double(beta), tri, row_off, col_off, ktri, ktile_off,
                nullptr, 0, nullptr, zrow, zcol_end, (ROLE == ROLE_DOWNDATE) ? 1 : 0};
+    g.img = img; g.img_nkc = img_nkc; g.img_c0 = img_c0;
     if (!st) st = stream;
     const bool mf = kIsF32 && opt_mfma;
     dim3 grid(cols / (mf ? TN : 64), rows / (mf ? TM : 64));
@@ -1649,6 +1654,7 @@ struct Filter : FilterBase {
       else chain_steps(step, cend[gi], c0, c1, m, m_pad, sc_, oneblock, opt_chain_defer && gi + 1 < nchunks);
       step = cend[gi];
       const int width = c1 - c0;
+      vimg_done = false;
       // the last chunk has nothing left to overlap with: it runs on the main stream, on every CU
       const bool overlap = (stream_b != nullptr) && (gi + 1 < nchunks);
       hipStream_t ss = overlap ? stream_b : stream;
@@ -1701,8 +1707,17 @@ struct Filter : FilterBase {
           solve_one_per_cu_now = false;
         } else if (kIsF32 && opt_mfma && wt * ntr < slots) {     // narrow chunk: 64-row tiles fill the chip
           const int* list = d_tilemap + solve64_off + 2 * (ntc - wt) * 2 * ntr;
+          // (round 6: when the bf16x6 downdate follows, the tiles also write the plane image of V_g it reads)
+          void* vimg = nullptr;
+          if constexpr (kIsF32) {
+            if (opt_fuse_split && opt_split_bf16 && tile == 128 && tri_count >= num_cus && counter_next + 16 <= kQueueCounters) {
+              if (!d_Vimg) HIPCHK(hipMalloc(&d_Vimg, (size_t)(n_pad + 128) * ldy * 6));
+              vimg = d_Vimg;
+              vimg_done = true;
+            }
+          }
           gemm<ROLE_SOLVE, true, 64, 128>(d_W + c0, ldy, Zs + c0, ldy, d_V + c0, ldy, npad_live + nb, width, width, T(1),
-                                          T(0), 0, 0, 0, 1, 0, ss, list, wt * 2 * ntr);
+                                          T(0), 0, 0, 0, 1, 0, ss, list, wt * 2 * ntr, 0, 0, vimg, ldy / 16, c0);
         } else {
           const int* list = d_tilemap + solve_off + 2 * (ntc - wt) * ntr;
           gemm<ROLE_SOLVE, true>(d_W + c0, ldy, Zs + c0, ldy, d_V + c0, ldy, npad_live + nb, width, width, T(1), T(0), 0,
@@ -1767,11 +1782,13 @@ struct Filter : FilterBase {
           // into the plane image (three bf16 per fp32, one 12 KB record per 128 rows x 16 columns), then the lower tiles
           // of Sigma are downdated from LDS-DMA-fed records
           if (!d_Vimg) HIPCHK(hipMalloc(&d_Vimg, (size_t)(n_pad + 128) * ldy * 6));
-          {
+          if (!vimg_done) {                                 // (the solve's tiles have written the image already)
             Scope sc(this, KID_MISC, ss);
+            ++launch_cnt[EKF_LAUNCH_SPLIT_IMAGE];
             dim3 grid(npad_live / 128, width / 16);
             k_split_image<<<grid, 256, 0, ss>>>(d_V, ldy, npad_live, c0, width, d_Vimg, ldy / 16);
           }
+          vimg_done = false;
           Scope sc(this, KID_DOWNDATE, ss);
           if (sc.on) prof_work[KID_DOWNDATE] += double(n) * n * (std::min(c1, m) - std::min(c0, m));
           Syrk6Args a{d_Vimg, ldy / 16, c0 / 16, width / 16, S(), ld, d_tilemap + tri6_off, tri_count, d_counters + counter_next,

@@ -462,6 +462,10 @@ struct GemmArgs {
   void* C2; int ldc2;
   int n2, nr2;
   int row2;                                     // first row tile of the second product (its tiles are rows row2 .. row2 + nr2 - 1)
+  // Optional (k_gemm_mfma<ROLE_SOLVE, .., 64, 128>): the tile also goes into the PLANE IMAGE of V the bf16x6 downdate reads
+  // (ekf_syrk6.hpp: three bf16 planes, 12 KB records), through LDS, with k_split_image's arithmetic -- the separate image
+  // launch behind every solve is gone (round 6; round 5 had measured it when the chain, not the second stream, bounded the step)
+  void* img = nullptr; int img_nkc = 0, img_c0 = 0;
 };
 constexpr int kSecondProduct = 0x10000;         // flag on bj for a tile of the second product
 constexpr int kHalfTile = 0x20000;              // flag on bi: 64-row half tile, bi & 0xffff in 64-row units (k_gemm_mfma, downdate)
@@ -800,7 +804,12 @@ __global__ void __launch_bounds__(S2 ? 512 : 256, S2 ? 1 : ((ROLE == ROLE_TRAILI
           }
     }
     __syncthreads();
-    if (grp == 1) return;
+    if (grp == 1) {
+      // (the first group meets once more when it also writes the plane image of the tile: every wave of the workgroup has to
+      // pass the same barriers before the next tile is drawn)
+      if ((ROLE == ROLE_SOLVE) && TMb == 64 && TN == 128 && g.img != nullptr) __syncthreads();
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -813,6 +822,11 @@ __global__ void __launch_bounds__(S2 ? 512 : 256, S2 ? 1 : ((ROLE == ROLE_TRAILI
         }
   }
   // epilogue: acc reg e of lane -> row (e&3) + 8*(e>>2) + 4*h, col l31 of the 32x32 tile
+  constexpr bool IMG = (ROLE == ROLE_SOLVE) && TMb == 64 && TN == 128;      // may also write the plane image of its tile
+  constexpr int SP = 132;                                                   // pitch of the staged tile (floats)
+  float* const stg = reinterpret_cast<float*>(lds);                         // 64 x 132 x 4 B = 33 KB of the (now idle) first group's stages
+  const bool to_img = IMG && g.img != nullptr;
+  if (to_img && !S2) __syncthreads();                                       // everybody is out of the K loop's stages (S2: the exchange's barriers)
   const bool mirror = (TMb == TN || SPLIT) && ((tri == 2 && grow0 >= gcol0 + TN) || (tri == 3 && listed_mirror));
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -833,6 +847,13 @@ __global__ void __launch_bounds__(S2 ? 512 : 256, S2 ? 1 : ((ROLE == ROLE_TRAILI
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e) C[(size_t)(rbase + (e & 3) + 8 * (e >> 2) + 4 * h) * ldc + c] = v[e];
+      if constexpr (IMG) {
+        if (to_img) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            stg[(wr * (TMb / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * SP + wc * (TN / WC) + j * 32 + l31] = v[e];
+        }
+      }
       if (mirror) {
         // 4 consecutive regs are 4 consecutive rows -> one 16-byte store into the transposed tile
         float* Ct = C + (size_t)(c + g.col_off - g.row_off) * ldc + (g.row_off - g.col_off);
@@ -843,6 +864,42 @@ __global__ void __launch_bounds__(S2 ? 512 : 256, S2 ? 1 : ((ROLE == ROLE_TRAILI
         }
       }
     }
+  if constexpr (IMG) {
+    if (to_img) {
+      // item = (row of the tile, octet of columns); consecutive lanes = consecutive rows: 1 KiB contiguous per plane
+      __syncthreads();                                   // (S2: the second group has left; the barrier counts live waves)
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      u32x4* const img = static_cast<u32x4*>(g.img);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = tid & 63, o = (tid >> 6) + 4 * it;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(stg + r * SP + 8 * o), x1 = *reinterpret_cast<const f32x4*>(stg + r * SP + 8 * o + 4);
+        const float a[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        unsigned short p0[8], p1[8], p2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const __bf16 a1 = (__bf16)a[e];
+          const float r1 = a[e] - (float)a1;
+          const __bf16 a2 = (__bf16)r1;
+          const float r2 = r1 - (float)a2;
+          const __bf16 a3 = (__bf16)r2;
+          p0[e] = __builtin_bit_cast(unsigned short, a1);
+          p1[e] = __builtin_bit_cast(unsigned short, a2);
+          p2[e] = __builtin_bit_cast(unsigned short, a3);
+        }
+        auto pack = [](const unsigned short* p) {
+          u32x4 v = {(unsigned)p[0] | ((unsigned)p[1] << 16), (unsigned)p[2] | ((unsigned)p[3] << 16),
+                     (unsigned)p[4] | ((unsigned)p[5] << 16), (unsigned)p[6] | ((unsigned)p[7] << 16)};
+          return v;
+        };
+        const int grow = g.row_off + bi * TMb + r, gc = g.img_c0 + bj * TN + 8 * o;
+        u32x4* rec = img + ((size_t)(grow >> 7) * g.img_nkc + (gc >> 4)) * 768 + ((gc >> 3) & 1) * 128 + (grow & 127);
+        rec[0] = pack(p0);
+        rec[256] = pack(p1);
+        rec[512] = pack(p2);
+      }
+    }
+  }
   };
   if constexpr (SPLIT) {
     listed_mirror = (bi & kMirrorTile) != 0;
