@@ -63,7 +63,7 @@ static const char* kLaunchNames[EKF_LAUNCH_KINDS] = {
     "downdate_bf16x6", "downdate_f32", "downdate_f32_fused_wu", "downdate_f32_half_tail", "downdate_f32_t64",
     "row_rider", "row_gemv", "row_tile_gemm", "w_update_gemm", "w_recompute",
     "chain_step_launches", "chain_persistent", "solve", "solve_two_groups", "update_oneblock", "update_allinone",
-    "chain_trail_diag", "split_image"};
+    "chain_trail_diag", "split_image", "state_update_tail"};
 
 static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
@@ -227,6 +227,7 @@ struct Filter : FilterBase {
   // the trailing update of step j and the diagonal factor of step j + 1 as ONE launch (k_trail_diag, ekf_chain.hpp);
   // EKF_CHAIN_FUSED_DIAG=0: diag -> panel -> trailing, three launches per block step (rounds 1-5; A/B and bit-identity check)
   int opt_chain_fused_diag = 1;
+  int opt_su_tail = 1;                                  // EKF_SU_TAIL=0: k_state_update as its own launch on the second stream beside the last downdate (round 5)
   int opt_fuse_split = 1;                               // EKF_FUSE_SPLIT=0: the plane image of V_g by its own launch behind the solve (rounds 5)
   bool vimg_done = false;                               // this chunk's solve has written the plane image of V_g
   int opt_chain_defer = 1;                              // EKF_CHAIN_DEFER=0: a chunk's event behind the trailing update of its last step (rounds 1-5)
@@ -235,7 +236,9 @@ struct Filter : FilterBase {
   std::vector<int> td_off, td_cnt;                      // per block step: its list of (I, K) blocks inside d_td_blocks
   int td_nblk = 0, td_nchunks = 0, td_cend[8] = {};
   int chain_diag_ahead = -1;                            // block step whose diagonal factor the last k_trail_diag launch has already done
-  int opt_syrk_stag_half = 0, opt_syrk_stag_mod4 = 0;   // EKF_SYRK_STAGGER="h,m": de-phasing of the bf16x6 downdate's workgroups (Syrk6Args)
+  // EKF_SYRK_STAGGER="h,m": de-phasing of the bf16x6 downdate's workgroups (Syrk6Args).  Round 6, N = 1000, knob A/B: every
+  // (0, m) with m = 1 .. 6 measures 0.897-0.903 ms per step against 0.917-0.922 without; a late second half (h > 0) gains nothing
+  int opt_syrk_stag_half = 0, opt_syrk_stag_mod4 = 2;
   // EKF_CHAIN_PERSISTENT=1: the chain as one look-ahead launch per column chunk (ekf_chain.hpp).  Bit-identical to the
   // per-step launches and NOT faster (round 6, measured: profiles/r6_chain_persistent_trace.txt): 45-50 us per block
   // step against 35-39 -- the critical workgroup moves ~360 KB per step through ONE CU, whose write-through stores run at
@@ -454,6 +457,7 @@ struct Filter : FilterBase {
       if (const char* e = getenv("EKF_CHAIN_PERSISTENT")) opt_chain_persistent = atoi(e) ? 1 : 0;
       if (const char* e = getenv("EKF_CHAIN_FUSED_DIAG")) opt_chain_fused_diag = atoi(e) ? 1 : 0;
       if (const char* e = getenv("EKF_FUSE_SPLIT")) opt_fuse_split = atoi(e) ? 1 : 0;
+      if (const char* e = getenv("EKF_SU_TAIL")) opt_su_tail = atoi(e) ? 1 : 0;
       if (const char* e = getenv("EKF_CHAIN_DEFER")) opt_chain_defer = atoi(e) ? 1 : 0;
       if (const char* e = getenv("EKF_TD_MIN_BLOCKS")) td_min_blocks = std::max(1, atoi(e));
       if (const char* e = getenv("EKF_CHAIN_TRACE")) {
@@ -1767,7 +1771,11 @@ struct Filter : FilterBase {
         HIPCHK(hipStreamWaitEvent(stream, ev_b, 0));
         b_inflight = false;
       }
-      if (!overlap && nchunks > 1) {
+      // (round 6: when the last downdate is the bf16x6 kernel, its workgroups take the state update's rows when they run out of
+      // tiles -- Syrk6Args::su_*: no launch, no second stream, no events at the end of the step)
+      bool su_tail = false;
+      if constexpr (kIsF32) su_tail = opt_su_tail && !overlap && nchunks > 1 && split_now;
+      if (!overlap && nchunks > 1 && !su_tail) {
         // every column of V and y = L^-1 nu exist now: the state update runs beside the last downdate
         HIPCHK(hipEventRecord(ev_chain[gi], stream));
         HIPCHK(hipStreamWaitEvent(stream_b, ev_chain[gi], 0));
@@ -1794,6 +1802,11 @@ struct Filter : FilterBase {
           Syrk6Args a{d_Vimg, ldy / 16, c0 / 16, width / 16, S(), ld, d_tilemap + tri6_off, tri_count, d_counters + counter_next,
                       0, 0, INT_MAX};
           a.stag_half = opt_syrk_stag_half; a.stag_mod4 = opt_syrk_stag_mod4;
+          if (su_tail) {
+            a.su_mu = mu(); a.su_V = d_V; a.su_ldy = ldy; a.su_n = n; a.su_y = d_V + (size_t)npad_live * ldy; a.su_mpad = m_pad;
+            a.su_qn = d_scr + SCR_QN; a.su_counter = d_counters + counter_next + 1;
+            ++launch_cnt[EKF_LAUNCH_STATE_UPDATE_TAIL];
+          }
           if (row_rider) {
             a.ry = d_V + (size_t)npad_live * ldy + c0; a.rL = Y + (size_t)c1 * ldy + c0; a.rldl = ldy;
             a.rnu = d_W + (size_t)npad_live * ldy + c1; a.rcols = m_pad - c1; a.rK = width; a.nrider = (m_pad - c1 + 255) / 256;
@@ -3090,6 +3103,7 @@ struct Filter : FilterBase {
             if (sc.on) prof_work[KID_DOWNDATE] += 2.0 * 128 * 128 * shard_syrk_n * double(std::min(c1, m) - std::min(c0, m));
             Syrk6Args a{d_Vimg, ldy / 16, c0 / 16, (c1 - c0) / 16, S(), ld, d_shard_syrk, shard_syrk_n, d_counters + counter_next,
                         camera_dim, r0, r1};
+            a.stag_half = opt_syrk_stag_half; a.stag_mod4 = opt_syrk_stag_mod4;
             if (sh_row_pending) {
               a.ry = d_V + (size_t)npad_live * ldy + c0; a.rL = d_Y + (size_t)c1 * ldy + c0; a.rldl = ldy;
               a.rnu = d_W + (size_t)npad_live * ldy + c1; a.rcols = m_pad - c1; a.rK = c1 - c0; a.nrider = (m_pad - c1 + 255) / 256;

@@ -2052,55 +2052,63 @@ __global__ void __launch_bounds__(64) k_innov_row_update(const float* __restrict
 // multiply (a 2048-column row is 8 KiB = 8 loads per lane, all outstanding at once); y comes through L1 / L2 (every
 // wave reads the same 8 KiB).  m_pad is a multiple of 64, so a sweep never runs past the padded row.
 // ---------------------------------------------------------------------------------------
+// One row of mu += V y by one wave (lane = 16 bytes of the row per sweep), and the quaternion normalisation behind it:
+// shared by k_state_update and by the workgroups of the last k_syrk_bf16x6 launch that run out of tiles (ekf_syrk6.hpp).
+template <typename T>
+__device__ __forceinline__ void state_update_row(T* __restrict__ mu, const T* __restrict__ V, int ldy, int row,
+                                                 const T* __restrict__ y, int m_pad, int lane) {
+  constexpr int VEC = 16 / sizeof(T);
+  typedef T vec_t __attribute__((ext_vector_type(VEC)));
+  const T* v = V + (size_t)row * ldy;
+  T acc = T(0);
+  constexpr int U = 8, SWEEP = 64 * VEC;
+  for (int c0 = lane * VEC; c0 < m_pad; c0 += U * SWEEP) {
+    vec_t a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u * SWEEP;
+      if (c < m_pad) {
+        a[u] = *reinterpret_cast<const vec_t*>(v + c);
+        b[u] = *reinterpret_cast<const vec_t*>(y + c);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (c0 + u * SWEEP < m_pad) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc += a[u][e] * b[u][e];
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) mu[row] += acc;
+}
+template <typename T>
+__device__ __forceinline__ void state_update_normalise(T* __restrict__ mu, T* __restrict__ scr_qn) {
+  const T q[4] = {mu[3], mu[4], mu[5], mu[6]};
+  const T nn = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  const T norma = t_sqrt(nn);
+  const T inv3 = T(1) / (norma * norma * norma);
+  for (int i = 0; i < 4; ++i) mu[3 + i] = q[i] / norma;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
+      scr_qn[i * 4 + j] = ((i == j ? norma * norma : T(0)) - q[i] * q[j]) * inv3;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(512)
 k_state_update(T* __restrict__ mu, const T* __restrict__ V, int ldy, int n,
                const T* __restrict__ y, int m_pad, T* __restrict__ scr_qn = nullptr) {
   // scr_qn != nullptr (launched with 512 lanes: rows 0..7 are workgroup 0): the workgroup that owns the quaternion
   // rows also normalises it and leaves Qn = (|q|^2 I - q q^T) / |q|^3 (4 x 4) at scr_qn (k_normalize_quat folded in).
-  constexpr int VEC = 16 / sizeof(T);
-  typedef T vec_t __attribute__((ext_vector_type(VEC)));
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (row < n) {
-    const T* v = V + (size_t)row * ldy;
-    T acc = T(0);
-    constexpr int U = 8, SWEEP = 64 * VEC;
-    for (int c0 = lane * VEC; c0 < m_pad; c0 += U * SWEEP) {
-      vec_t a[U], b[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int c = c0 + u * SWEEP;
-        if (c < m_pad) {
-          a[u] = *reinterpret_cast<const vec_t*>(v + c);
-          b[u] = *reinterpret_cast<const vec_t*>(y + c);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (c0 + u * SWEEP < m_pad) {
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) acc += a[u][e] * b[u][e];
-        }
-      }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    if (lane == 0) mu[row] += acc;
-  }
+  if (row < n) state_update_row(mu, V, ldy, row, y, m_pad, lane);
   if (scr_qn != nullptr && blockIdx.x == 0) {
     __threadfence_block();
     __syncthreads();                             // rows 3..6 are written (workgroup 0 holds rows 0..7)
-    if (threadIdx.x == 0) {
-      const T q[4] = {mu[3], mu[4], mu[5], mu[6]};
-      const T nn = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
-      const T norma = t_sqrt(nn);
-      const T inv3 = T(1) / (norma * norma * norma);
-      for (int i = 0; i < 4; ++i) mu[3 + i] = q[i] / norma;
-      for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j)
-          scr_qn[i * 4 + j] = ((i == j ? norma * norma : T(0)) - q[i] * q[j]) * inv3;
-    }
+    if (threadIdx.x == 0) state_update_normalise(mu, scr_qn);
   }
 }
 

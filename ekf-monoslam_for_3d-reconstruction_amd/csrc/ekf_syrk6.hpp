@@ -91,6 +91,12 @@ struct Syrk6Args {
   // workgroup of a CU (the second half of the grid) starts stag_half x 0.85 us late, and workgroup b another (b & 3) x
   // stag_mod4 x 0.85 us: the two workgroups of a CU alternate between K loop and epilogue, and the C traffic of the chip is spread.
   int stag_half = 0, stag_mod4 = 0;
+  // Tail filler (round 6, the LAST downdate of an update): a workgroup that finds no tile left takes rows of the state update
+  // mu += V y (16 rows per ticket of a second counter, one wave per row: k_state_update's sums) instead of leaving; ticket 0
+  // holds the quaternion rows and normalises them (Qn -> su_qn).  The launch no longer ends with idle CUs waiting for its
+  // slowest tiles, and the state update needs neither a launch nor a second stream.
+  float* su_mu = nullptr; const float* su_V = nullptr; int su_ldy = 0, su_n = 0; const float* su_y = nullptr; int su_mpad = 0;
+  float* su_qn = nullptr; int* su_counter = nullptr;
 };
 
 // Every element pair {r, c}, r >= c, is computed ONCE, as element (r, c) of its canonical tile (A block = the block of r,
@@ -348,6 +354,26 @@ __global__ void __launch_bounds__(256, 2) k_syrk_bf16x6(Syrk6Args g) {
     }
     have = have_next;
     cur = nxt;
+  }
+  if (g.su_mu != nullptr) {
+    const int nsu = (g.su_n + 15) / 16;
+    for (;;) {
+      __syncthreads();
+      if (tid == 0) s_next[0] = atomicAdd(g.su_counter, 1);
+      __syncthreads();
+      const int tk = __builtin_amdgcn_readfirstlane(s_next[0]);
+      if (tk >= nsu) break;
+#pragma unroll 1
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int row = 16 * tk + 4 * wave + r4;
+        if (row < g.su_n) state_update_row(g.su_mu, g.su_V, g.su_ldy, row, g.su_y, g.su_mpad, lane);
+      }
+      if (tk == 0 && g.su_qn != nullptr) {
+        __threadfence_block();
+        __syncthreads();                           // rows 3 .. 6 are written (this workgroup holds rows 0 .. 15)
+        if (tid == 0) state_update_normalise(g.su_mu, g.su_qn);
+      }
+    }
   }
 }
 

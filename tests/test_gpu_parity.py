@@ -928,7 +928,8 @@ def test_w_recompute_agrees_with_the_right_looking_w_update():
     ({"EKF_CHAIN_FUSED_DIAG": "0"}, ("chain_step_launches", "chain_trail_diag")),       # round 6: trailing update + next diagonal factor as one launch (default) against three launches per step
     ({"EKF_SPLIT_BF16": "0", "EKF_CHAIN_FUSED_DIAG": "0"}, ("chain_step_launches", "chain_trail_diag")),
     ({"EKF_TD_MIN_BLOCKS": "1"}, ("chain_trail_diag",)),
-    ({"EKF_FUSE_SPLIT": "0"}, ("split_image",)),                                        # round 6: the plane image of V_g written by the solve's tiles against its own launch
+    ({"EKF_FUSE_SPLIT": "0"}, ("split_image",)),
+    ({"EKF_SU_TAIL": "0"}, ("state_update_tail",)),                                     # round 6: mu += V y by the last downdate's idle workgroups against its own launch                                        # round 6: the plane image of V_g written by the solve's tiles against its own launch
     ({"EKF_CHAIN_DEFER": "0"}, ()),                                                     # a chunk's event behind / in front of its last trailing update: the same launches                                # ... for every step, however few blocks its update has
     ({"EKF_CHAIN_PERSISTENT": "1"}, ("chain_step_launches", "chain_persistent")),       # round 6: the look-ahead chain kernel (opt-in) against the per-step launches
     ({"EKF_SPLIT_BF16": "0", "EKF_CHAIN_PERSISTENT": "1"}, ("chain_step_launches", "chain_persistent")),
@@ -951,7 +952,7 @@ def test_launch_structure_knobs_are_bit_identical(monkeypatch, knobs, differs):
     base = {k: v for k, v in knobs.items() if k in common}
     all_knobs = ("EKF_SPLIT_TAIL", "EKF_FUSE_WU", "EKF_W_RECOMPUTE", "EKF_SPLIT_BF16", "EKF_ROW_GEMV", "EKF_RESERVED_CUS",
                  "EKF_CHAIN_PERSISTENT", "EKF_CHUNKS", "EKF_CHAIN_FUSED_DIAG", "EKF_TD_MIN_BLOCKS", "EKF_FUSE_SPLIT",
-                 "EKF_CHAIN_DEFER")
+                 "EKF_CHAIN_DEFER", "EKF_SU_TAIL")
     for env in (base, knobs):
         for k in all_knobs:
             monkeypatch.delenv(k, raising=False)
