@@ -5,6 +5,7 @@ step the span of the bulk work, and the waiting / computing / publishing totals.
 import os, sys
 import numpy as np
 os.environ["EKF_CHAIN_TRACE"] = "1"
+os.environ["EKF_CHAIN_PERSISTENT"] = "1"          # (opt-in since the measurement this tool made: DESIGN 5)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT]
 from __graft_entry__ import load_package
