@@ -232,6 +232,7 @@ struct Filter : FilterBase {
   bool vimg_done = false;                               // this chunk's solve has written the plane image of V_g
   int opt_chain_defer = 1;                              // EKF_CHAIN_DEFER=0: a chunk's event behind the trailing update of its last step (rounds 1-5)
   int td_min_blocks = 24;                               // EKF_TD_MIN_BLOCKS: steps with fewer blocks in their update keep the three launches
+  int td_max_blocks = 1 << 30;                          // EKF_TD_MAX_BLOCKS: ... and so do steps with more (many rounds of blocks: the 64 x 64 tile kernel's occupancy wins)
   int* d_td_blocks = nullptr;
   std::vector<int> td_off, td_cnt;                      // per block step: its list of (I, K) blocks inside d_td_blocks
   int td_nblk = 0, td_nchunks = 0, td_cend[8] = {};
@@ -460,6 +461,7 @@ struct Filter : FilterBase {
       if (const char* e = getenv("EKF_SU_TAIL")) opt_su_tail = atoi(e) ? 1 : 0;
       if (const char* e = getenv("EKF_CHAIN_DEFER")) opt_chain_defer = atoi(e) ? 1 : 0;
       if (const char* e = getenv("EKF_TD_MIN_BLOCKS")) td_min_blocks = std::max(1, atoi(e));
+      if (const char* e = getenv("EKF_TD_MAX_BLOCKS")) td_max_blocks = std::max(1, atoi(e));
       if (const char* e = getenv("EKF_CHAIN_TRACE")) {
         if (atoi(e)) HIPCHK(hipMalloc(&d_chain_trace, (size_t)(8 + 8 * kChainTraceCap) * sizeof(unsigned)));
       }
@@ -1475,7 +1477,8 @@ struct Filter : FilterBase {
   // true: launched (and the factor of step + 1 is done); false: this step keeps the separate launches
   bool launch_trail_diag(int step, int m, hipStream_t sc_) {
     if constexpr (kIsF32) {
-      if (!trail_diag_ok() || NB() != 128 || td_nblk == 0 || step + 1 >= td_nblk || td_cnt[step] < td_min_blocks)
+      if (!trail_diag_ok() || NB() != 128 || td_nblk == 0 || step + 1 >= td_nblk || td_cnt[step] < td_min_blocks ||
+          td_cnt[step] > td_max_blocks)
         return false;
       TrailDiagArgs a{};
       a.Y = d_Y; a.ldy = ldy; a.y_bytes = (unsigned)((size_t)2 * ldy * ldy * sizeof(T));
@@ -2869,6 +2872,11 @@ struct Filter : FilterBase {
     if (const char* e = getenv("EKF_SHARD_FORCE_COLLECTIVE")) sh_force = (atoi(e) != 0) && fn != nullptr;
     if (const char* e = getenv("EKF_SHARD_SYM")) opt_shard_sym = atoi(e);
     if (const char* e = getenv("EKF_DEBUG_SYNC")) dbg_sync = atoi(e);
+    // From four ranks on the REPLICATED chain, not the rank's share of the GEMMs, is what a step of a long list waits for
+    // (DESIGN 6): steps with many rounds of trailing blocks then go back to the 64 x 64 tile kernel, whose occupancy makes the
+    // chain's own kernel time 21 % shorter at N = 4000 (13.6 -> 10.7 ms at world 1, profiles/r6_shard_world1_nccl_n4000*.json) at
+    // the price of the exposed factor -- on one or two ranks the chain is hidden beside the downdate and the fused launch wins.
+    if (world >= 4 && !getenv("EKF_TD_MAX_BLOCKS")) td_max_blocks = 256;
     if (!stream_g) {
       HIPCHK(hipStreamCreateWithFlags(&stream_g, hipStreamNonBlocking));
       for (auto& e : ev_gath) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
