@@ -17,6 +17,7 @@
 #include "ekf_image.hpp"
 #include "ekf_syrk6.hpp"
 #include "ekf_chain.hpp"
+#include "ekf_small.hpp"
 #include "ekf_kernels.hpp"
 #include "ekf_shard.hpp"
 
@@ -63,7 +64,7 @@ static const char* kLaunchNames[EKF_LAUNCH_KINDS] = {
     "downdate_bf16x6", "downdate_f32", "downdate_f32_fused_wu", "downdate_f32_half_tail", "downdate_f32_t64",
     "row_rider", "row_gemv", "row_tile_gemm", "w_update_gemm", "w_recompute",
     "chain_step_launches", "chain_persistent", "solve", "solve_two_groups", "update_oneblock", "update_allinone",
-    "chain_trail_diag", "split_image", "state_update_tail"};
+    "chain_trail_diag", "split_image", "state_update_tail", "update_onelaunch"};
 
 static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
@@ -227,6 +228,11 @@ struct Filter : FilterBase {
   // the trailing update of step j and the diagonal factor of step j + 1 as ONE launch (k_trail_diag, ekf_chain.hpp);
   // EKF_CHAIN_FUSED_DIAG=0: diag -> panel -> trailing, three launches per block step (rounds 1-5; A/B and bit-identity check)
   int opt_chain_fused_diag = 1;
+  // the whole update of a small map (n_pad <= 256, one diagonal block) as ONE launch (k_update_small_onelaunch, ekf_small.hpp);
+  // EKF_SMALL_ONELAUNCH=0: W, S, the factor and the rest as four launches (rounds 3-5; A/B and bit-identity check)
+  int opt_small_onelaunch = 1;
+  unsigned long long* d_small_stamps = nullptr;         // EKF_SMALL_STAMPS=1: phase stamps of its workgroup 0 (ekf_peek_workspace, which = 3)
+  unsigned small_gate_total = 0;                        // arrivals the gate word (d_status[9]) has seen when every launch so far is over
   int opt_su_tail = 1;                                  // EKF_SU_TAIL=0: k_state_update as its own launch on the second stream beside the last downdate (round 5)
   int opt_fuse_split = 1;                               // EKF_FUSE_SPLIT=0: the plane image of V_g by its own launch behind the solve (rounds 5)
   bool vimg_done = false;                               // this chunk's solve has written the plane image of V_g
@@ -299,7 +305,7 @@ struct Filter : FilterBase {
                     d_status, d_tmp, d_K, d_tilemap, d_counters, d_ibuf, d_rmask, d_pts, d_tab,
                     d_frame, d_patch[0], d_patch[1], d_mpatch[0], d_mpatch[1], d_hb, d_zm, d_found, d_score, d_keep,
                     d_Vimg, d_stage_send, d_stage_recv, d_archive, d_arch_idx, d_panel_tiles, d_shard_solve, d_shard_syrk,
-                    d_chain_tasks, d_chain_flags, d_chain_trace, d_td_blocks};
+                    d_chain_tasks, d_chain_flags, d_chain_trace, d_td_blocks, d_small_stamps};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int s = 0; s < kInSlots; ++s) { if (h_in[s]) hipHostFree(h_in[s]); if (ev_in[s]) hipEventDestroy(ev_in[s]); }
     if (h_pred) hipHostFree(h_pred);
@@ -418,7 +424,7 @@ struct Filter : FilterBase {
     HIPCHK(hipMalloc(&d_Dinv, (size_t)(ldy / 64) * 128 * 128 * sizeof(T)));
     HIPCHK(hipMalloc(&d_z, (size_t)ldy * sizeof(T)));
     HIPCHK(hipMalloc(&d_midx, cn * sizeof(int)));
-    HIPCHK(hipMalloc(&d_status, 16 * sizeof(int)));         // [0] pivot <= 0, [1] bad device index list, [3] a bounded device-side wait gave up; [4..7] scratch of ekf_check_invariants; [8] arrival gate of k_predict_fused
+    HIPCHK(hipMalloc(&d_status, 16 * sizeof(int)));         // [0] pivot <= 0, [1] bad device index list, [3] a bounded device-side wait gave up; [4..7] scratch of ekf_check_invariants; [8] arrival gate of k_predict_fused, [9] of k_update_small_onelaunch
     HIPCHK(hipMemsetAsync(d_status, 0, 16 * sizeof(int), stream));
     HIPCHK(hipMalloc(&d_tmp, 64 * sizeof(T)));
     HIPCHK(hipMalloc(&d_counters, kQueueCounters * sizeof(int)));
@@ -459,6 +465,10 @@ struct Filter : FilterBase {
       if (const char* e = getenv("EKF_CHAIN_FUSED_DIAG")) opt_chain_fused_diag = atoi(e) ? 1 : 0;
       if (const char* e = getenv("EKF_FUSE_SPLIT")) opt_fuse_split = atoi(e) ? 1 : 0;
       if (const char* e = getenv("EKF_SU_TAIL")) opt_su_tail = atoi(e) ? 1 : 0;
+      if (const char* e = getenv("EKF_SMALL_ONELAUNCH")) opt_small_onelaunch = atoi(e) ? 1 : 0;
+      if (const char* e = getenv("EKF_SMALL_STAMPS")) {
+        if (atoi(e)) { HIPCHK(hipMalloc(&d_small_stamps, 16 * sizeof(unsigned long long))); HIPCHK(hipMemset(d_small_stamps, 0, 16 * sizeof(unsigned long long))); }
+      }
       if (const char* e = getenv("EKF_CHAIN_DEFER")) opt_chain_defer = atoi(e) ? 1 : 0;
       if (const char* e = getenv("EKF_TD_MIN_BLOCKS")) td_min_blocks = std::max(1, atoi(e));
       if (const char* e = getenv("EKF_TD_MAX_BLOCKS")) td_max_blocks = std::max(1, atoi(e));
@@ -625,7 +635,8 @@ struct Filter : FilterBase {
         // the arrival gate of k_predict_fused was left mid-count: every launch that could still add to it has to be
         // over before it is cleared, and the fused predict launch stays off for this filter from here on
         HIPCHK(hipStreamSynchronize(stream));
-        HIPCHK(hipMemsetAsync(d_status + 8, 0, sizeof(int), stream));
+        HIPCHK(hipMemsetAsync(d_status + 8, 0, 2 * sizeof(int), stream));      // ... and the gate of k_update_small_onelaunch
+        small_gate_total = 0;
         opt_fused = 0;
         FAIL(EKF_ERR_DEVICE, "a bounded device-side wait gave up (fused launch); EKF_OPT_FUSED_LAUNCHES is now off for this filter");
       }
@@ -1625,12 +1636,45 @@ struct Filter : FilterBase {
     // Linv of the diagonal factor, so the panel launch, the solve and the state update are ONE launch
     // (k_solve_state_oneblock; small maps: the downdate and the normalisation too, k_update_oneblock_small): the step is
     // launch-bound there.
-    bool oneblock = false, allinone = false;
+    bool oneblock = false, allinone = false;                // (allinone: downdate + normalisation are in the launch too)
     if constexpr (kIsF32)
       oneblock = opt_fused && opt_mfma && nchunks == 1 && m_pad == 128 && nb == 128 && !prof_on(KID_SOLVE) &&
                  !prof_on(KID_STATE_UPDATE) && !prof_on(KID_CHOL_PANEL);
     const int* ip_list = cur_midx ? cur_midx : d_midx;    // the measured list (device memory), for the re-evaluations of W below
-    int rc = build_innovation(M, plane, true, &m, &m_pad, &tab, strip_rows);
+    // Small map (n_pad <= 256: the reference's 20-35 features): W, S, the factor, the solve, the state update, the downdate
+    // and the normalisation as ONE launch (ekf_small.hpp) -- every workgroup forms W, S and the factor for itself
+    bool onelaunch = false;
+    int rc = EKF_OK;
+    if constexpr (kIsF32) {
+      const int nt64 = (npad_live / 64) * (npad_live / 64 + 1) / 2;
+      int small_rc = 0, small_nchunk = 0;
+      onelaunch = oneblock && opt_small_onelaunch && npad_live <= kSmallMaxRows && nt64 <= num_cus && ld % 4 == 0 &&
+                  small_chunking(n, round_up(m, 4), &small_rc, &small_nchunk) && M <= 62 && !prof_on(KID_SIGMA_HT) &&
+                  !prof_on(KID_INNOVATION_COV) && !prof_on(KID_CHOL_DIAG) && !prof_on(KID_DOWNDATE) && !prof_on(KID_NORMALIZE);
+      if (onelaunch) {
+        if (w_zeroed_n != n) {              // (what build_innovation keeps: pad rows of W and the rows behind nu are zero)
+          HIPCHK(hipMemsetAsync(d_W + (size_t)n * ldy, 0, (size_t)(npad_live - n + nb) * ldy * sizeof(T), stream));
+          w_zeroed_n = n;
+        }
+        counter_next = 0;
+        SmallUpdateArgs a{};
+        a.S = S(); a.ld = ld; a.n = n; a.npad = npad_live;
+        a.Hc = d_Hc; a.Hf = d_Hf; a.pos = d_pos; a.coding = d_coding; a.midx = ip_list;
+        a.M = M; a.plane = plane; a.nfeat = N;
+        a.z = cur_z ? cur_z : d_z; a.h = d_h; a.mu = mu();
+        a.r_pix = T(sigma_pixel_2); a.r_plane = T(0.00001);
+        a.W = d_W; a.ldw = ldy; a.Y = d_Y; a.ldy = ldy; a.Dinv = d_Dinv; a.V = d_V; a.ldv = ldy;
+        a.scr_qn = d_scr + SCR_QN; a.status = d_status;
+        a.gate = reinterpret_cast<unsigned*>(d_status + 9);
+        small_gate_total += (unsigned)(nt64 + 1);
+        a.gate_target = small_gate_total;
+        a.ntiles = nt64; a.wp = round_up(m, 4); a.stamps = d_small_stamps;
+        a.rc = small_rc; a.nchunk = small_nchunk;
+        ++launch_cnt[EKF_LAUNCH_UPDATE_ONELAUNCH];
+        k_update_small_onelaunch<<<nt64 + 1, 1024, 0, stream>>>(a);
+      }
+    }
+    if (!onelaunch) rc = build_innovation(M, plane, true, &m, &m_pad, &tab, strip_rows);
     cur_z = nullptr;
     cur_midx = nullptr;
     if (rc) return rc;
@@ -1653,7 +1697,8 @@ struct Filter : FilterBase {
     chain_pending.step = -1;
     td_nblk = (td_nblk == nsteps) ? td_nblk : 0;
     if (!pchain && !oneblock && trail_diag_ok() && nb == 128 && nsteps >= 2) { rc = ensure_trail_diag_lists(nsteps, nchunks, cend); if (rc) return rc; }
-    for (int gi = 0; gi < nchunks; ++gi) {
+    if (onelaunch) allinone = true;
+    for (int gi = 0; gi < (onelaunch ? 0 : nchunks); ++gi) {
       const int c0 = step * nb, c1 = cend[gi] * nb;
       // chunk 0 has the chip to itself; later chunks run beside the tile GEMMs of stream_b, on the reserved CUs
       hipStream_t sc_ = stream;
@@ -2025,6 +2070,14 @@ struct Filter : FilterBase {
       if (cols != 8 || r0 < -1 || rows < 0 || r0 + rows > kChainTraceCap) FAIL(EKF_ERR_ARG, "trace block out of range");
       HIPCHK(hipDeviceSynchronize());
       HIPCHK(hipMemcpy(out, d_chain_trace + 8 * (size_t)(r0 + 1), (size_t)rows * 8 * sizeof(unsigned), hipMemcpyDeviceToHost));
+      return EKF_OK;
+    }
+    if (which == 3) {
+      // the phase stamps of k_update_small_onelaunch (EKF_SMALL_STAMPS=1): 16 64-bit words (rows = 16, cols = 2 32-bit halves)
+      if (!d_small_stamps) FAIL(EKF_ERR_STATE, "no stamps (create the filter with EKF_SMALL_STAMPS=1)");
+      if (rows != 16 || cols != 2 || r0 != 0 || c0 != 0) FAIL(EKF_ERR_ARG, "stamp block out of range");
+      HIPCHK(hipDeviceSynchronize());
+      HIPCHK(hipMemcpy(out, d_small_stamps, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
       return EKF_OK;
     }
     if (which < 0 || which > 1) FAIL(EKF_ERR_ARG, "workspace id out of range");

@@ -980,6 +980,64 @@ def test_launch_structure_knobs_are_bit_identical(monkeypatch, knobs, differs):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("n_feat,stride,plane,nxyz,expect", [
+    (8, 1, False, 0, True), (20, 1, True, 0, True), (32, 1, True, 0, True), (32, 2, False, 3, True),
+    (21, 3, True, 1, True), (35, 1, True, 2, True), (35, 1, False, 0, True),
+    (40, 1, True, 0, False),                               # n = 254, m = 83: the W image does not fit the LDS -> four launches
+])
+def test_small_map_onelaunch_update_is_bit_identical(monkeypatch, n_feat, stride, plane, nxyz, expect):
+    """Round 6: the update of a small map (n_pad <= 256, the reference's 20-35 features) is ONE launch
+    (k_update_small_onelaunch: every workgroup forms W, S and the factor for itself, then its own tile) instead of four.
+    Every sum is formed by the instruction sequence of the kernel it replaces: mu, Sigma, the gain and the workspaces W
+    and V (ekf_peek_workspace) equal the four-launch path (EKF_SMALL_ONELAUNCH=0) to the last bit -- all measured and
+    subsets, with and without the plane rows, with XYZ features in the list -- and the launch counters prove which
+    path ran."""
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from ekf_monoslam_amd import synthetic
+    cfg = pkg.kinect_config()
+    frames = 4
+    px0, z = synthetic.measurement_stream(cfg, n_feat, frames, sigma_px=0.5)
+    idx = np.arange(0, n_feat, stride, dtype=np.int32)
+    outs, counts = [], []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("EKF_SMALL_ONELAUNCH", mode)
+        f = pkg.VSlamFilter(cfg, capacity_features=n_feat)
+        f.setDt(1.0 / 30.0)
+        for (u, v) in px0:
+            assert f.addFeature((u, v)) == 1
+        per_frame = []
+        for k in range(frames):
+            if k == 1 and nxyz:
+                pos, _ = f.featureLayout()
+                nn = f.stateDim()
+                for fi in range(1, 1 + 2 * nxyz, 2):          # force some features through the linearity test: a known depth
+                    r = int(pos[fi]) + 5
+                    f.setSigmaBlock(np.zeros((1, nn), np.float32), r, 0)
+                    f.setSigmaBlock(np.zeros((nn, 1), np.float32), 0, r)
+                    f.setSigmaBlock(np.array([[1e-9]], np.float32), r, r)
+                assert f.convert2XYZ_ifLinearAll() == nxyz
+            f.predict()
+            f.update(z[k][idx].reshape(-1), idx, plane_constraint=plane)
+            n = f.stateDim()
+            npad = (n + 127) // 128 * 128
+            per_frame.append((f.getFullState(), f.getFullSigma(), f.getGain(), f.peekWorkspace(0, 0, 0, npad + 1, 128),
+                              f.peekWorkspace(1, 0, 0, npad + 1, 128)))
+        assert f.checkInvariants()[0] == 0.0
+        outs.append(per_frame)
+        counts.append(f.launch_counts())
+        f.close()
+    monkeypatch.delenv("EKF_SMALL_ONELAUNCH", raising=False)
+    assert counts[0]["update_onelaunch"] == 0 and counts[0]["update_allinone"] == frames, counts[0]
+    if expect:
+        assert counts[1]["update_onelaunch"] == frames and counts[1]["update_allinone"] == 0, counts[1]
+    else:
+        assert counts[1]["update_onelaunch"] == 0 and counts[1]["update_allinone"] == frames, counts[1]
+    for k in range(frames):
+        for name, a0, a1 in zip(("mu", "Sigma", "gain", "W", "V"), outs[0][k], outs[1][k]):
+            assert np.array_equal(a0, a1), (k, name, float(np.max(np.abs(a0.astype(np.float64) - a1))))
+
+
 def test_chunk_plan_knob_changes_rounding_only(monkeypatch):
     """EKF_CHUNKS (where the column chunks of the factorisation end) is NOT a bit-identity knob: another plan is another
     order of the sequential form (which columns of W are re-evaluated from which downdated Sigma).  Same update up to fp32
