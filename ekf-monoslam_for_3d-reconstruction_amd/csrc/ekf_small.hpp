@@ -27,10 +27,11 @@
 // (W as n x WP at its end, then V_i | V_j as 64 x 132 each at its front), 143 KB, + 15 KB of small arrays.
 //
 // Measured (tools/small_stamps.py, profiles/r6_small_onelaunch.txt; N = 32, plane rows, n = 206, m = 67): the launch takes
-// 29 us (front loads 2.3, W 7.0, S 2.4, factor 9.3, y + operands 1.6, V 1.8, products 1.7, tile epilogue 2.7); predict +
-// update 39.6 us against 43.2 with the four launches.  VERDICT r5's "<= 25 us per step" is out of reach for this
-// structure: the factor of the 67 x 67 innovation (five 16-column blocks of the LDS-resident blocked Cholesky, 1.85 us
-// each -- the same rate as in the chain of large maps) and the 7 us predict launch in front are 16 us by themselves.
+// 29.7 us (front loads 2.3, W 7.4, S 2.4, factor 9.2, y + operands 1.7, V 1.8, products 1.7, tile epilogue 2.7); predict +
+// update 39.6 us against 42.9 with the four launches (N = 20: 32.8 against 40.4).  VERDICT r5's "<= 25 us per step" is out
+// of reach for this structure: the factor of the 67 x 67 innovation (five 16-column blocks of the LDS-resident blocked
+// Cholesky, 1.85 us each -- the same rate as in the chain of large maps) and the 7 us predict launch in front are 16 us
+// by themselves.
 #pragma once
 #include "ekf_dense.hpp"
 
@@ -54,7 +55,7 @@ struct SmallUpdateArgs {
   unsigned* gate; unsigned gate_target;
   int ntiles;                                    // 64 x 64 lower tiles; workgroup ntiles holds the nu row
   int wp;                                        // pitch of the W image: m rounded up to 4
-  int rc, nchunk;                                // rows of Sigma staged at a time (<= 80), number of such chunks (<= 4): small_chunking()
+  int rc, nchunk;                                // rows of Sigma staged at a time (<= 64), number of such chunks (<= 4): small_chunking()
   unsigned long long* stamps;                    // diagnostics (EKF_SMALL_STAMPS=1): 100 MHz clock of workgroup 0 at the phase boundaries
 };
 
@@ -70,7 +71,7 @@ inline bool small_chunking(int n, int wp, int* rc, int* nchunk) {
   if ((long)n * wp > kSmallImg) return false;
   for (int c = 1; c <= 4; ++c) {
     const int r = (n + c - 1) / c;
-    if (r <= 80 && (long)r * sp <= cap) { *rc = r; *nchunk = c; return true; }
+    if (r <= 64 && (long)r * sp <= cap) { *rc = r; *nchunk = c; return true; }
   }
   return false;
 }
@@ -114,15 +115,16 @@ __global__ void __launch_bounds__(1024, 1) k_update_small_onelaunch(SmallUpdateA
   const int rb = wave >> 2, cb = wave & 3;       // the wave's 16 x 16 block of the tile
 
   EKF_SMALL_STAMP(0);
-  // ---- the rows of Sigma, RC at a time: wave w takes rows w, w + 16, ... of a chunk (up to five), lane = 16 bytes of the
-  // row (coalesced).  Two chunks are in flight (svA: even chunks, svB: odd ones): chunk c + 2 is requested as soon as
-  // chunk c has gone to LDS, and the barriers of this phase wait for LDS only, never for those loads --------------------
+  // ---- the rows of Sigma, RC at a time: wave w takes rows w, w + 16, ... of a chunk (up to four), lane = 16 bytes of the
+  // row (coalesced).  Three chunks are requested at once (a request made one chunk ahead arrives too late: a round trip is
+  // ~1.8 us, a chunk's work less); a fourth follows chunk 0 in its registers, and the barriers of this phase wait for LDS
+  // only, never for that load -------------------------------------------------------------------------------------------
   const int nq = (n + 3) >> 2;
   const int RC = g.rc, nchunk = g.nchunk;
-  f4 svA[5], svB[5];
-  auto load_chunk = [&](f4 (&buf)[5], int ch) {
+  f4 svA[4], svB[4], svC[4];
+  auto load_chunk = [&](f4 (&buf)[4], int ch) {
 #pragma unroll
-    for (int pp = 0; pp < 5; ++pp) {
+    for (int pp = 0; pp < 4; ++pp) {
       const int rr = wave + 16 * pp, row = RC * ch + rr;
       buf[pp] = f4{0.f, 0.f, 0.f, 0.f};
       if (rr < RC && row < n && lane < nq) buf[pp] = *reinterpret_cast<const f4*>(g.S + (size_t)row * g.ld + 4 * lane);
@@ -131,6 +133,7 @@ __global__ void __launch_bounds__(1024, 1) k_update_small_onelaunch(SmallUpdateA
   auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); };
   load_chunk(svA, 0);
   if (nchunk > 1) load_chunk(svB, 1);
+  if (nchunk > 2) load_chunk(svC, 2);
   // what this workgroup alone will overwrite, requested with everything else (a load issued later would be waited for
   // at the next barrier: ~1.3 us each time): the Sigma values of the wave's block of the tile, the owner's rows of mu
   float cin[4] = {0.f, 0.f, 0.f, 0.f};
@@ -191,7 +194,7 @@ __global__ void __launch_bounds__(1024, 1) k_update_small_onelaunch(SmallUpdateA
   bool all_even = true;
   auto w_chunk = [&](auto CH) {
     constexpr int ch = decltype(CH)::value;
-    f4 (&buf)[5] = (ch & 1) ? svB : svA;
+    f4 (&buf)[4] = (ch == 1) ? svB : ((ch == 2) ? svC : svA);   // (chunk 3, if there is one, follows chunk 0 in svA)
     if (ch == 0) __syncthreads(); else lds_barrier();          // the rows of the chunk before are consumed (first pass: the lists are in LDS)
     if (ch == 0) {
 #pragma unroll
@@ -215,16 +218,16 @@ __global__ void __launch_bounds__(1024, 1) k_update_small_onelaunch(SmallUpdateA
     }
     if (lane < nq) {
 #pragma unroll
-      for (int pp = 0; pp < 5; ++pp)
+      for (int pp = 0; pp < 4; ++pp)
         if (wave + 16 * pp < RC) *reinterpret_cast<f4*>(a + (wave + 16 * pp) * SP + 4 * lane) = buf[pp];
     }
     if (tid == 0) *reinterpret_cast<f4*>(a + RC * SP) = f4{0.f, 0.f, 0.f, 0.f};
-    if (ch + 2 < nchunk) load_chunk(buf, ch + 2);
+    if (ch == 0 && nchunk > 3) load_chunk(buf, 3);
     lds_barrier();
     EKF_SMALL_STAMP(11 + ch);                    // chunk ch is staged (chunk 0: the loads have arrived)
     typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int j2 = 0; j2 < 3; ++j2) {             // two rows (two independent pairs of chains) at a time
+    for (int j2 = 0; j2 < 2; ++j2) {             // two rows (two independent pairs of chains) at a time
       if (wave + 32 * j2 >= RC) break;
       f4 c0[2], c1[2];
       float fv[2][6];
