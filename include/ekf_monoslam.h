@@ -302,7 +302,9 @@ int ekf_set_sigma_block(ekf_filter* f, const void* in, int r0, int c0, int rows,
  * which = 2 (round 6; a filter created with EKF_CHAIN_TRACE=1 in the environment): the task trace of the persistent chain
  * kernel of the last update -- `rows` records of 8 32-bit words from record r0 on (cols = 8; r0 = -1 starts at the header,
  * whose word 0 counts the records): type | workgroup << 8 | critical << 24, block step, row block, column block, and the
- * 100 MHz wall clock at draw / dependencies met / computed / published (tools/chain_trace.py). */
+ * 100 MHz wall clock at draw / dependencies met / computed / published (tools/chain_trace.py).
+ * which = 3 (round 6; EKF_SMALL_STAMPS=1): the phase stamps of the one-launch update of a small map (k_update_small_onelaunch):
+ * 16 64-bit words of the 100 MHz clock as rows = 16, cols = 2 32-bit halves, r0 = c0 = 0 (tools/small_stamps.py). */
 int ekf_peek_workspace(ekf_filter* f, int which, void* out, int r0, int c0, int rows, int cols);
 /* Covariance_Parameter (vR.cpp:841-866): trace of Sigma[0:7,0:7]. */
 int ekf_covariance_parameter(ekf_filter* f, double* out);
