@@ -15,6 +15,7 @@ cd /tmp && export TMPDIR=/tmp
 STAGE="${1:-A}"
 if [ "$STAGE" = A ]; then
 echo "bench N=1000"; python3 "$R/bench.py" > "$O/${P}_bench.json" 2> "$O/bench.err"
+echo "bench with the driver's arguments"; python3 "$R/bench.py" --gpus 1 --steps 20 --warmup 5 > "$O/${P}_bench_driver_args.json" 2>> "$O/bench.err"
 echo "bench N=200 x 1000 frames"; python3 "$R/bench.py" --features 200 --steps 1000 --warmup 10 --no-cpu-baseline > "$O/${P}_bench_n200_1000frames.json" 2>> "$O/bench.err"
 echo "bench N=4000"; python3 "$R/bench.py" --features 4000 --steps 20 --warmup 3 --no-cpu-baseline --no-propagate-pass > "$O/${P}_bench_n4000.json" 2>> "$O/bench.err"
 echo "rocprofv3 kernel stats (the timed run of the default bench line)"; rm -rf "$O/prof"
