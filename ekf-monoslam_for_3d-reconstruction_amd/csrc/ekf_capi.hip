@@ -64,7 +64,7 @@ static const char* kLaunchNames[EKF_LAUNCH_KINDS] = {
     "downdate_bf16x6", "downdate_f32", "downdate_f32_fused_wu", "downdate_f32_half_tail", "downdate_f32_t64",
     "row_rider", "row_gemv", "row_tile_gemm", "w_update_gemm", "w_recompute",
     "chain_step_launches", "chain_persistent", "solve", "solve_two_groups", "update_oneblock", "update_allinone",
-    "chain_trail_diag", "split_image", "state_update_tail", "update_onelaunch"};
+    "chain_trail_diag", "split_image", "state_update_tail", "update_onelaunch", "chain_dist_gather"};
 
 static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
@@ -305,7 +305,8 @@ struct Filter : FilterBase {
                     d_status, d_tmp, d_K, d_tilemap, d_counters, d_ibuf, d_rmask, d_pts, d_tab,
                     d_frame, d_patch[0], d_patch[1], d_mpatch[0], d_mpatch[1], d_hb, d_zm, d_found, d_score, d_keep,
                     d_Vimg, d_stage_send, d_stage_recv, d_archive, d_arch_idx, d_panel_tiles, d_shard_solve, d_shard_syrk,
-                    d_chain_tasks, d_chain_flags, d_chain_trace, d_td_blocks, d_small_stamps};
+                    d_chain_tasks, d_chain_flags, d_chain_trace, d_td_blocks, d_small_stamps,
+                    d_dist_lists, d_dist_counters, d_dist_send, d_dist_recv};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int s = 0; s < kInSlots; ++s) { if (h_in[s]) hipHostFree(h_in[s]); if (ev_in[s]) hipEventDestroy(ev_in[s]); }
     if (h_pred) hipHostFree(h_pred);
@@ -466,6 +467,8 @@ struct Filter : FilterBase {
       if (const char* e = getenv("EKF_FUSE_SPLIT")) opt_fuse_split = atoi(e) ? 1 : 0;
       if (const char* e = getenv("EKF_SU_TAIL")) opt_su_tail = atoi(e) ? 1 : 0;
       if (const char* e = getenv("EKF_SMALL_ONELAUNCH")) opt_small_onelaunch = atoi(e) ? 1 : 0;
+      if (const char* e = getenv("EKF_SHARD_DIST_CHAIN")) opt_shard_dist_chain = atoi(e) ? 1 : 0;
+      if (const char* e = getenv("EKF_SHARD_DIST_MIN_BLOCKS")) shard_dist_min_blocks = std::max(2, atoi(e));
       if (const char* e = getenv("EKF_SMALL_STAMPS")) {
         if (atoi(e)) { HIPCHK(hipMalloc(&d_small_stamps, 16 * sizeof(unsigned long long))); HIPCHK(hipMemset(d_small_stamps, 0, 16 * sizeof(unsigned long long))); }
       }
@@ -2482,6 +2485,148 @@ struct Filter : FilterBase {
     }
   }
 
+  // ---- distributed chain of the sharded step -----------------------------------------------------------
+  // From `shard_dist_min_blocks` block steps on the factorisation of S is no longer replicated: rank r OWNS the 128-row
+  // blocks I of S with I % world == r (cyclic: the triangle's work is balanced) and keeps only those rows of the trailing
+  // matrix up to date -- plus every diagonal block and the chunk's inverse strip, which every rank updates for itself (one
+  // block per remaining step and the strip: cheap, and it saves a broadcast per step).  Block step j:
+  //   every rank   factor of the diagonal block (j, j)                       (redundant: 17 us, no exchange)
+  //   rank r       panel P(j; I) = S(I, j) Linv_jj^T for its own I > j and for the strip rows
+  //   ALL-GATHER   of the own panel blocks: afterwards every rank holds all of column block j of L
+  //   rank r       trailing update of its own row blocks, of all diagonal blocks (K, K), K > j, and of the strip
+  // Every tile is the plain path's tile (k_panel_direct's product, k_gemm_mfma<TRAILING, 64, 64>'s sums): L, the strips and
+  // therefore the whole update are bit-identical to the replicated chain's, whoever computed a tile.
+  int opt_shard_dist_chain = 1;                          // EKF_SHARD_DIST_CHAIN=0: the replicated chain at every size
+  int shard_dist_min_blocks = 32;                        // EKF_SHARD_DIST_MIN_BLOCKS (N = 2000: 32 steps)
+  struct DistPlan {
+    int nblk = 0, nchunks = 0, cend[8] = {0, 0, 0, 0, 0, 0, 0, 0}, world = 0, rank = -1;
+    std::vector<int> pb_off, pb_own, pb_cnt, tl_off, tl_cnt, slot_blocks;
+  } dist;
+  int* d_dist_lists = nullptr;
+  int* d_dist_counters = nullptr;
+  int dist_counters_cap = 0;
+  T *d_dist_send = nullptr, *d_dist_recv = nullptr;
+  size_t dist_slot = 0;
+  bool dist_chain_ok(int nsteps) const {
+    return kIsF32 && opt_mfma && opt_shard_dist_chain && sh_on && exchanges() && NB() == 128 && nsteps >= shard_dist_min_blocks;
+  }
+  int ensure_dist_plan(int nblk, int nchunks, const int* cend) {
+    bool same = dist.nblk == nblk && dist.nchunks == nchunks && dist.world == sh_world && dist.rank == sh_rank;
+    for (int g = 0; same && g < nchunks; ++g) same = dist.cend[g] == cend[g];
+    if (!same) {
+      std::vector<int> all;
+      dist.pb_off.assign(nblk, 0); dist.pb_own.assign(nblk, 0); dist.pb_cnt.assign(nblk, 0);
+      dist.tl_off.assign(nblk, 0); dist.tl_cnt.assign(nblk, 0); dist.slot_blocks.assign(nblk, 0);
+      int maxslot = 0;
+      for (int j = 0; j < nblk; ++j) {
+        int s0 = 0, s1 = nblk;
+        for (int g = 0; g < nchunks; ++g)
+          if (j < cend[g]) { s0 = g ? cend[g - 1] : 0; s1 = cend[g]; break; }
+        dist.pb_off[j] = (int)all.size();
+        for (int I = j + 1; I < nblk; ++I)
+          if (I % sh_world == sh_rank) all.push_back(I);
+        dist.pb_own[j] = (int)all.size() - dist.pb_off[j];
+        for (int t = 0; t <= j - s0; ++t) all.push_back(nblk + t);
+        dist.pb_cnt[j] = (int)all.size() - dist.pb_off[j];
+        for (int g = 0; g < sh_world; ++g) {
+          const int first = j + 1 + ((g - (j + 1)) % sh_world + sh_world) % sh_world;
+          const int cnt = first < nblk ? (nblk - 1 - first) / sh_world + 1 : 0;
+          dist.slot_blocks[j] = std::max(dist.slot_blocks[j], cnt);
+        }
+        maxslot = std::max(maxslot, dist.slot_blocks[j]);
+        dist.tl_off[j] = (int)all.size();
+        for (int I = j + 1; I < nblk; ++I) {             // 64 x 64 tiles relative to row / column block j + 1
+          const int d = I - j - 1;
+          if (I % sh_world == sh_rank) {
+            for (int bi = 2 * d; bi < 2 * d + 2; ++bi)
+              for (int bj = 0; bj <= bi; ++bj) { all.push_back(bi); all.push_back(bj); }
+          } else {                                       // somebody else's rows: the diagonal block only
+            all.push_back(2 * d); all.push_back(2 * d);
+            all.push_back(2 * d + 1); all.push_back(2 * d);
+            all.push_back(2 * d + 1); all.push_back(2 * d + 1);
+          }
+        }
+        for (int t = 0; t <= j - s0; ++t) {              // the strip rows of the chunk: columns up to the chunk's end
+          const int rb = nblk - j - 1 + t;
+          for (int bi = 2 * rb; bi < 2 * rb + 2; ++bi)
+            for (int bj = 0; bj < 2 * (s1 - j - 1); ++bj) { all.push_back(bi); all.push_back(bj); }
+        }
+        dist.tl_cnt[j] = ((int)all.size() - dist.tl_off[j]) / 2;
+      }
+      HIPCHK(hipStreamSynchronize(stream));
+      if (stream_b) HIPCHK(hipStreamSynchronize(stream_b));
+      if (d_dist_lists) HIPCHK(hipFree(d_dist_lists));
+      d_dist_lists = nullptr;
+      HIPCHK(hipMalloc(&d_dist_lists, std::max<size_t>(all.size(), 1) * sizeof(int)));
+      HIPCHK(hipMemcpy(d_dist_lists, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice));
+      if (nblk * 8 > dist_counters_cap) {
+        if (d_dist_counters) HIPCHK(hipFree(d_dist_counters));
+        d_dist_counters = nullptr;
+        dist_counters_cap = nblk * 8;
+        HIPCHK(hipMalloc(&d_dist_counters, (size_t)dist_counters_cap * sizeof(int)));
+      }
+      const size_t slot = (size_t)std::max(maxslot, 1) * 128 * 128;
+      if (slot > dist_slot) {
+        if (d_dist_send) HIPCHK(hipFree(d_dist_send));
+        if (d_dist_recv) HIPCHK(hipFree(d_dist_recv));
+        d_dist_send = d_dist_recv = nullptr;
+        HIPCHK(hipMalloc(&d_dist_send, slot * sizeof(T)));
+        HIPCHK(hipMalloc(&d_dist_recv, slot * sizeof(T) * sh_world));
+        dist_slot = slot;
+      }
+      dist.nblk = nblk; dist.nchunks = nchunks; dist.world = sh_world; dist.rank = sh_rank;
+      for (int g = 0; g < nchunks; ++g) dist.cend[g] = cend[g];
+    }
+    HIPCHK(hipMemsetAsync(d_dist_counters, 0, (size_t)nblk * 8 * sizeof(int), stream));
+    return EKF_OK;
+  }
+  // block steps [step0, step1) of the distributed chain on stream st (no deferral, no fused launches: a step ends with its
+  // trailing update)
+  int dist_chain_steps(int step0, int step1, int m, int m_pad, hipStream_t st) {
+    if constexpr (kIsF32) {
+      T* Y = d_Y;
+      const int nblk = dist.nblk;
+      for (int step = step0; step < step1; ++step) {
+        const int j = step * 128, r0 = j + 128;
+        T* Dj = d_Dinv + (size_t)step * 128 * 128;
+        {
+          Scope sc(this, KID_CHOL_DIAG, st);
+          ++launch_cnt[EKF_LAUNCH_CHAIN_STEP];
+          k_chol_diag_packed<><<<1, 1024, 0, st>>>(Y + (size_t)j * ldy + j, ldy, Dj, d_status, std::max(1, std::min(8, (m - j + 15) / 16)));
+        }
+        const int* pb = d_dist_lists + dist.pb_off[step];
+        if (dist.pb_cnt[step] > 0) {
+          Scope sc(this, KID_CHOL_PANEL, st);
+          ++launch_cnt[EKF_LAUNCH_CHAIN_STEP];
+          k_panel_direct_blocks<<<2 * dist.pb_cnt[step], 256, 0, st>>>(Y + j, ldy, Dj, pb);
+        }
+        if (dist.slot_blocks[step] > 0) {
+          Scope sc(this, KID_GATHER_S, st);
+          const size_t slot = (size_t)dist.slot_blocks[step] * 128 * 128;
+          if (dist.pb_own[step] > 0)
+            k_dist_pack_panel<T><<<128 * dist.pb_own[step], 32, 0, st>>>(Y + j, ldy, pb, dist.pb_own[step], d_dist_send);
+          ++launch_cnt[EKF_LAUNCH_CHAIN_DIST_GATHER];
+          const int rc = sh_ag(sh_ctx, d_dist_send, d_dist_recv, slot * sizeof(T), st);
+          if (rc != 0) FAIL(EKF_ERR_DEVICE, "the all-gather callback reported a failure");
+          if (sh_world > 1)
+            k_dist_unpack_panel<T><<<dim3(128 * dist.slot_blocks[step], 1, sh_world), 32, 0, st>>>(d_dist_recv, slot, Y + j, ldy, step,
+                                                                                               nblk, sh_world, sh_rank);
+        }
+        if (dist.tl_cnt[step] > 0) {
+          Scope sc(this, KID_CHOL_TRAILING, st);
+          ++launch_cnt[EKF_LAUNCH_CHAIN_STEP];
+          const T* P = Y + (size_t)r0 * ldy + j;
+          GemmArgs g{P, ldy, P, ldy, Y + (size_t)r0 * ldy + r0, ldy, 128, -1.0, 1.0, 0, r0, r0, 0, 0,
+                     d_dist_lists + dist.tl_off[step], dist.tl_cnt[step], d_dist_counters + 8 * step, 0, 0, 0};
+          k_gemm_mfma<ROLE_TRAILING, false, 64, 64><<<std::min(dist.tl_cnt[step], 2 * num_cus), 256, 0, st>>>(g);
+        }
+      }
+      HIPCHK(hipGetLastError());
+    }
+    (void)m_pad;
+    return EKF_OK;
+  }
+
   int ensure_stage(size_t slot_elems) {
     if (slot_elems <= stage_slot) return EKF_OK;
     HIPCHK(hipStreamSynchronize(stream));
@@ -3208,16 +3353,19 @@ struct Filter : FilterBase {
     if constexpr (kIsF32) sh_rec = opt_mfma && opt_wrecompute && nb == 128 && nchunks > 1;
     int step = 0;
     bool side_busy = false;
-    const bool pchain = chain_persistent_ok() && nb == 128 && nsteps >= 2;
+    const bool dchain = dist_chain_ok(nsteps);             // the factorisation distributed over the ranks (see dist_chain_steps)
+    const bool pchain = !dchain && chain_persistent_ok() && nb == 128 && nsteps >= 2;
     if (pchain) { rc = chain_begin_update(nsteps, nchunks, cend); if (rc) return rc; }
+    if (dchain) { rc = ensure_dist_plan(nsteps, nchunks, cend); if (rc) return rc; }
     chain_diag_ahead = -1;
     chain_pending.step = -1;
     td_nblk = (td_nblk == nsteps) ? td_nblk : 0;
-    if (!pchain && trail_diag_ok() && nb == 128 && nsteps >= 2) { rc = ensure_trail_diag_lists(nsteps, nchunks, cend); if (rc) return rc; }
+    if (!pchain && !dchain && trail_diag_ok() && nb == 128 && nsteps >= 2) { rc = ensure_trail_diag_lists(nsteps, nchunks, cend); if (rc) return rc; }
     int pend_c0 = -1, pend_c1 = -1, pend_g = -1;           // overlapped chunk whose downdate is still to be issued
     for (int gi = 0; gi < nchunks; ++gi) {
       const int c0 = step * nb, c1 = cend[gi] * nb, width = c1 - c0;
       if (pchain) { rc = chain_launch(gi, m, gi == 0, stream); if (rc) return rc; }
+      else if (dchain) { rc = dist_chain_steps(step, cend[gi], m, m_pad, stream); if (rc) return rc; }
       else chain_steps(step, cend[gi], c0, c1, m, m_pad, stream, false, opt_chain_defer && gi + 1 < nchunks);
       step = cend[gi];
       const bool overlap = (gi + 1 < nchunks);

@@ -1585,14 +1585,15 @@ k_chol_diag_packed(float* __restrict__ Aglob, int ld, float* __restrict__ Dinv, 
 // triangular): 144 MFMAs per wave instead of 256.  Replaces the 64 x 128 tile-GEMM launch of the general kernel
 // (K = 128 is four of its K steps: prologue, epilogue and barriers dominated).
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2) k_panel_direct(float* __restrict__ P, int ldp, const float* __restrict__ Dinv, int rows) {
+// (the body: workgroup `wg` = rows 64 wg .. of P; shared by the plain launch and by the launch over a LIST of 128-row blocks)
+__device__ __forceinline__ void panel_direct_body(float* __restrict__ P, int ldp, const float* __restrict__ Dinv, int rows, int wg,
+                                                  float* sl) {
   constexpr int NB = 128, PITCH = 132;
   typedef float f4 __attribute__((ext_vector_type(4)));
-  __shared__ float sl[NB * PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   __builtin_amdgcn_s_setprio(2);                 // part of the serial chain
-  const int row0 = blockIdx.x * 64 + wave * 16;
+  const int row0 = wg * 64 + wave * 16;
   const bool live = row0 < rows;
   // the wave's rows: A[row0 + lr][16 u + 4 lq ..]
   f4 fa[8];
@@ -1647,6 +1648,18 @@ __global__ void __launch_bounds__(256, 2) k_panel_direct(float* __restrict__ P, 
   }
   __syncthreads();
   if (live) column_tiles(4);
+}
+__global__ void __launch_bounds__(256, 2) k_panel_direct(float* __restrict__ P, int ldp, const float* __restrict__ Dinv, int rows) {
+  __shared__ float sl[128 * 132];
+  panel_direct_body(P, ldp, Dinv, rows, blockIdx.x, sl);
+}
+// The same product for a LIST of 128-row blocks of a column block (the distributed chain of the sharded step: a rank's own row
+// blocks are not contiguous): workgroups 2 b, 2 b + 1 = the two halves of block blocks[b]; Pcol = row 0 of the column block.
+__global__ void __launch_bounds__(256, 2) k_panel_direct_blocks(float* __restrict__ Pcol, int ldp, const float* __restrict__ Dinv,
+                                                               const int* __restrict__ blocks) {
+  __shared__ float sl[128 * 132];
+  const int blk = blocks[blockIdx.x >> 1];
+  panel_direct_body(Pcol + (size_t)blk * 128 * ldp, ldp, Dinv, 128, blockIdx.x & 1, sl);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -52,6 +52,41 @@ __global__ void k_unpack_rows(const T* __restrict__ recv, size_t slot_elems, int
   }
 }
 
+// ---- distributed chain (a rank owns the 128-row blocks I of S with I % world == rank): the panel of block step j --------
+// own blocks of column block j -> the send slot ([block][128][128], the order of the list)
+template <typename T>
+__global__ void k_dist_pack_panel(const T* __restrict__ Ycol, int ld, const int* __restrict__ blocks, int nblocks,
+                                  T* __restrict__ dst) {
+  constexpr int V = 16 / sizeof(T);
+  typedef T vec_t __attribute__((ext_vector_type(V)));
+  const int row = blockIdx.x;                      // 0 .. 128 nblocks
+  if (row >= 128 * nblocks) return;
+  const int b = row >> 7, r = row & 127;
+  const T* s = Ycol + (size_t)(blocks[b] * 128 + r) * ld;
+  T* d = dst + (size_t)row * 128;
+  for (int c = threadIdx.x; c < 128 / V; c += blockDim.x)
+    *reinterpret_cast<vec_t*>(d + (size_t)c * V) = *reinterpret_cast<const vec_t*>(s + (size_t)c * V);
+}
+// slot g of recv holds rank g's blocks of this step in ascending order: I = first(g), first(g) + world, ... < nblk with
+// first(g) the smallest I > j, I % world == g.  Everybody else's blocks go to their rows of the column block.
+template <typename T>
+__global__ void k_dist_unpack_panel(const T* __restrict__ recv, size_t slot_elems, T* __restrict__ Ycol, int ld, int j, int nblk,
+                                    int world, int self) {
+  constexpr int V = 16 / sizeof(T);
+  typedef T vec_t __attribute__((ext_vector_type(V)));
+  const int g = blockIdx.z;
+  if (g == self) return;
+  int first = j + 1 + ((g - (j + 1)) % world + world) % world;
+  const int cnt = first < nblk ? (nblk - 1 - first) / world + 1 : 0;
+  const int row = blockIdx.x;
+  if (row >= 128 * cnt) return;
+  const int b = row >> 7, r = row & 127;
+  const T* s = recv + (size_t)g * slot_elems + (size_t)row * 128;
+  T* d = Ycol + (size_t)((first + b * world) * 128 + r) * ld;
+  for (int c = threadIdx.x; c < 128 / V; c += blockDim.x)
+    *reinterpret_cast<vec_t*>(d + (size_t)c * V) = *reinterpret_cast<const vec_t*>(s + (size_t)c * V);
+}
+
 // Per-feature record of the "reassemble H" exchange: [h (2) | Hc (14) | Hf (12) | flag (1)] = 29 scalars.
 constexpr int kFeatRec = 32;       // padded to 32 scalars: records stay 16-byte aligned
 

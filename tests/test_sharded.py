@@ -379,6 +379,62 @@ def test_hip_shard_full_size_matches_plain_path(world, n_feat):
     assert seen.all()
 
 
+def _gpu_env_worker(rank, world, port, n_feat, frames, z_np, px0, env, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.update(env)                                   # tuning knobs are read when the filter is created
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from ekf_monoslam_amd import sharded
+    flt = _mk_hip(pkg, n_feat, px0)
+    sharded.configure(flt, rank, world)
+    d_z = torch.from_numpy(z_np).cuda()
+    idx = np.arange(n_feat, dtype=np.int32)
+    for k in range(frames):
+        flt.predict()
+        sharded.shard_update(flt, d_z[k].data_ptr(), idx)
+    flt.synchronize()
+    info = sharded.shard_info(flt)
+    rows = np.r_[0:14, info.row_begin:info.row_end]
+    out[rank] = (flt.getFullState(), rows, flt.getFullSigma()[rows], flt.getGain()[rows], flt.launch_counts())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n_feat", [(2, 330), (3, 601), (5, 400)])
+def test_hip_shard_distributed_chain_is_bit_identical(world, n_feat):
+    """Round 6: from 32 block steps on the factorisation of S is DISTRIBUTED -- a rank keeps only its
+    own 128-row blocks of the trailing matrix (cyclic), every diagonal block and the inverse strip up to date, and one
+    all-gather per block step hands the panel round (`Filter::dist_chain_steps`).  Every tile is the replicated chain's
+    tile, so mu, the rank's rows of Sigma and the gain (which needs ALL of L on every rank) equal the replicated chain's
+    to the last bit.  Forced on here at 6-10 block steps (EKF_SHARD_DIST_MIN_BLOCKS=2), several chunks, uneven ownership
+    (block counts not divisible by the world size), ranks that own no block of the last steps."""
+    frames = 2
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from ekf_monoslam_amd import synthetic
+    px0, z = synthetic.measurement_stream(pkg.kinect_config(), n_feat, frames, sigma_px=0.5)
+    z_np = np.ascontiguousarray(z.reshape(frames, -1), np.float32)
+    runs = []
+    for env in ({"EKF_SHARD_DIST_CHAIN": "0"}, {"EKF_SHARD_DIST_CHAIN": "1", "EKF_SHARD_DIST_MIN_BLOCKS": "2"}):
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_gpu_env_worker, args=(world, free_port(), n_feat, frames, z_np, px0, env, out), nprocs=world, join=True)
+        runs.append({r: out[r] for r in range(world)})
+    nblk = (2 * n_feat + 127) // 128
+    for rank in range(world):
+        mu0, rows0, S0, K0, c0 = runs[0][rank]
+        mu1, rows1, S1, K1, c1 = runs[1][rank]
+        assert c0["chain_dist_gather"] == 0 and c1["chain_dist_gather"] == frames * (nblk - 1), (c0, c1)
+        assert np.array_equal(rows0, rows1)
+        assert np.all(np.isfinite(mu1)) and np.all(np.isfinite(S1))
+        assert np.array_equal(mu0, mu1), float(np.max(np.abs(mu0 - mu1)))
+        assert np.array_equal(S0, S1), float(np.max(np.abs(S0 - S1)))
+        assert np.array_equal(K0, K1), float(np.max(np.abs(K0 - K1)))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 5])
 def test_hip_shard_n1000_ranks_match_fp64_oracle(world):
