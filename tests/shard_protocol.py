@@ -43,8 +43,9 @@ class ShardProtocol:
     """The sharded step over a backend that does the arithmetic of ONE rank on numpy arrays (tests/sharded_common.py:
     the structured oracle with everything a rank does not own poisoned with NaN)."""
 
-    def __init__(self, backend, rank, world):
+    def __init__(self, backend, rank, world, dist_chain=False):
         self.b, self.rank, self.world = backend, rank, world
+        self.dist_chain = dist_chain                          # the factorisation distributed over the ranks (round 6)
         self.fb = partition_by_rows(backend.positions(), backend.n, backend.camera_dim, world)
         self.rebalances = 0
         backend.set_owner(self.own_features(), self.own_rows())
@@ -149,7 +150,11 @@ class ShardProtocol:
         for g in range(self.world):
             if g != self.rank:
                 b.set_S_rows(2 * kr[g][0], parts[g])
-        b.factor()                                            # replicated chain (incl. the plane / tail rows)
+        if self.dist_chain:                                   # one all-gather of the panel per block step
+            b.factor_distributed(self.rank, self.world,
+                                 lambda own, counts: _all_gather_padded(own, counts, self.rank, self.world))
+        else:
+            b.factor()                                        # replicated chain (incl. the plane / tail rows)
         m = b.m
         ends = sorted(set([m * (c + 1) // chunks for c in range(chunks)]))
         c0 = 0

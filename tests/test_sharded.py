@@ -129,7 +129,7 @@ def cpu_scenario(make_driver, n_feat, frames, world=1, rank=0):
     return fobj
 
 
-def _cpu_worker(rank, world, port, n_feat, frames, out):
+def _cpu_worker(rank, world, port, n_feat, frames, out, dist_chain=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -141,7 +141,7 @@ def _cpu_worker(rank, world, port, n_feat, frames, out):
 
     def make(f):
         b = OracleShardBackend(f)
-        p = ShardProtocol(b, rank, world)
+        p = ShardProtocol(b, rank, world, dist_chain=dist_chain)
         holder["p"] = p
         return p, f
     f = cpu_scenario(make, n_feat, frames, world, rank)
@@ -153,16 +153,20 @@ def _cpu_worker(rank, world, port, n_feat, frames, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_feat", [(2, 9), (4, 14), (4, 3), (8, 24), (8, 5)])
-def test_shard_protocol_matches_unsharded_oracle_gloo(world, n_feat):
+@pytest.mark.parametrize("world,n_feat,dist_chain", [(2, 9, False), (4, 14, False), (4, 3, False), (8, 24, False), (8, 5, False),
+                                                      (2, 9, True), (4, 14, True), (8, 24, True), (8, 5, True)])
+def test_shard_protocol_matches_unsharded_oracle_gloo(world, n_feat, dist_chain):
     """Uneven partitions (9 over 2, 14 over 4, 3 features over 4 ranks: an empty rank; world 8 = the node BASELINE
     configs[3] / [4] name: 24 features, and 5 features over 8 ranks: three empty ranks), subsets, plane rows, XYZ
-    conversions, removals and additions, re-balance: every rank's rows must equal the unsharded oracle."""
+    conversions, removals and additions, re-balance: every rank's rows must equal the unsharded oracle.
+    dist_chain (round 6): the factorisation of S distributed over the ranks -- cyclic row blocks, one all-gather of the panel
+    per block step, every rank reading only what it owns or was handed (the rest is NaN in the model) -- with a block of
+    2 rows, so that the lists of this test run 5-25 block steps and ranks regularly own nothing of a step."""
     frames = 7
     ref = cpu_scenario(lambda f: (PlainOracle(f), f), n_feat, frames)
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_cpu_worker, args=(world, free_port(), n_feat, frames, out), nprocs=world, join=True)
+    mp.spawn(_cpu_worker, args=(world, free_port(), n_feat, frames, out, dist_chain), nprocs=world, join=True)
     seen = np.zeros(ref.n, bool)
     for rank in range(world):
         mu, rows, S_rows, rebal, fb, coding = out[rank]
@@ -774,7 +778,7 @@ def _gpu_n4000_worker(rank, world, port, out):
     rows = np.r_[0:14, info.row_begin:min(info.row_begin + 200, info.row_end), max(info.row_begin, info.row_end - 200):info.row_end]
     blocks = [flt.getSigmaBlock(int(r), 0, 1, flt.stateDim()) for r in rows[::7]]
     out[rank] = (flt.getFullState(), rows[::7], np.concatenate(blocks), (info.f_begin, info.f_end), pad, flt.numOfFeatures(),
-                 info.rebalances)
+                 info.rebalances, flt.launch_counts()["chain_dist_gather"])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -813,8 +817,11 @@ def test_hip_shard_n4000_resize_cadence_two_ranks_match_plain_path():
     mp.spawn(_gpu_n4000_worker, args=(2, free_port(), out), nprocs=2, join=True)
     ranges = []
     for rank in range(2):
-        mu, rows, S_rows, frange, pad, nfeat, rebal = out[rank]
+        mu, rows, S_rows, frange, pad, nfeat, rebal, dist_gathers = out[rank]
         assert nfeat == N and mu.shape == (n,) and np.all(np.isfinite(mu)) and pad == 0.0
+        # round 6: at this size (~60 block steps) the ranks run the DISTRIBUTED chain (one all-gather of the panel per block
+        # step, Filter::dist_chain_steps); the plain path it is compared with factors S in one place
+        assert dist_gathers > 50 * N4000_FRAMES, dist_gathers
         ref_rows = np.concatenate([flt.getSigmaBlock(int(r), 0, 1, n) for r in rows])
         # bit-identical after 101 frames and two resizes -- or the ONE documented deviation of this rig (ranks sharing a
         # GPU: an anchor coordinate off by < 1e-7 about once in 400 updates, helpers.exact_or_anchor_glitch)
