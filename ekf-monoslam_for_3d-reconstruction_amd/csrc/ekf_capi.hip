@@ -2486,7 +2486,7 @@ struct Filter : FilterBase {
   }
 
   // ---- distributed chain of the sharded step -----------------------------------------------------------
-  // From `shard_dist_min_blocks` block steps on the factorisation of S is no longer replicated: rank r OWNS the 128-row
+  // From `shard_dist_min_blocks` block steps on (and two ranks or more) the factorisation of S is no longer replicated: rank r OWNS the 128-row
   // blocks I of S with I % world == r (cyclic: the triangle's work is balanced) and keeps only those rows of the trailing
   // matrix up to date -- plus every diagonal block and the chunk's inverse strip, which every rank updates for itself (one
   // block per remaining step and the strip: cheap, and it saves a broadcast per step).  Block step j:
@@ -2497,10 +2497,14 @@ struct Filter : FilterBase {
   // Every tile is the plain path's tile (k_panel_direct's product, k_gemm_mfma<TRAILING, 64, 64>'s sums): L, the strips and
   // therefore the whole update are bit-identical to the replicated chain's, whoever computed a tile.
   int opt_shard_dist_chain = 1;                          // EKF_SHARD_DIST_CHAIN=0: the replicated chain at every size
-  int shard_dist_min_blocks = 32;                        // EKF_SHARD_DIST_MIN_BLOCKS (N = 2000: 32 steps)
+  // EKF_SHARD_DIST_MIN_BLOCKS: 40 block steps (N = 2500).  Per step the distributed form pays ~25 us of stand-alone factor and
+  // ~35 us of gather where the replicated one pays the whole trailing update; measured on one rank (profiles/
+  // r6_shard_world1_dist_chain.txt) the two meet at 32 steps for 8 ranks (2.1 ms each) and the distributed one wins above
+  int shard_dist_min_blocks = 40;
   struct DistPlan {
     int nblk = 0, nchunks = 0, cend[8] = {0, 0, 0, 0, 0, 0, 0, 0}, world = 0, rank = -1;
     std::vector<int> pb_off, pb_own, pb_cnt, tl_off, tl_cnt, slot_blocks;
+    std::vector<int> tb_off, tb_cnt;                     // the same update as (I, K) pairs of 128 x 128 blocks, without (j + 1, j + 1): k_trail_diag
   } dist;
   int* d_dist_lists = nullptr;
   int* d_dist_counters = nullptr;
@@ -2517,6 +2521,7 @@ struct Filter : FilterBase {
       std::vector<int> all;
       dist.pb_off.assign(nblk, 0); dist.pb_own.assign(nblk, 0); dist.pb_cnt.assign(nblk, 0);
       dist.tl_off.assign(nblk, 0); dist.tl_cnt.assign(nblk, 0); dist.slot_blocks.assign(nblk, 0);
+      dist.tb_off.assign(nblk, 0); dist.tb_cnt.assign(nblk, 0);
       int maxslot = 0;
       for (int j = 0; j < nblk; ++j) {
         int s0 = 0, s1 = nblk;
@@ -2552,6 +2557,18 @@ struct Filter : FilterBase {
             for (int bj = 0; bj < 2 * (s1 - j - 1); ++bj) { all.push_back(bi); all.push_back(bj); }
         }
         dist.tl_cnt[j] = ((int)all.size() - dist.tl_off[j]) / 2;
+        dist.tb_off[j] = (int)all.size();
+        for (int I = j + 1; I < nblk; ++I) {
+          if (I % sh_world == sh_rank) {
+            for (int K = j + 1; K <= I; ++K)
+              if (!(I == j + 1 && K == j + 1)) { all.push_back(I); all.push_back(K); }
+          } else if (I != j + 1) {
+            all.push_back(I); all.push_back(I);
+          }
+        }
+        for (int t = 0; t <= j - s0; ++t)
+          for (int K = j + 1; K < s1; ++K) { all.push_back(nblk + t); all.push_back(K); }
+        dist.tb_cnt[j] = ((int)all.size() - dist.tb_off[j]) / 2;
       }
       HIPCHK(hipStreamSynchronize(stream));
       if (stream_b) HIPCHK(hipStreamSynchronize(stream_b));
@@ -2589,7 +2606,7 @@ struct Filter : FilterBase {
       for (int step = step0; step < step1; ++step) {
         const int j = step * 128, r0 = j + 128;
         T* Dj = d_Dinv + (size_t)step * 128 * 128;
-        {
+        if (chain_diag_ahead != step) {
           Scope sc(this, KID_CHOL_DIAG, st);
           ++launch_cnt[EKF_LAUNCH_CHAIN_STEP];
           k_chol_diag_packed<><<<1, 1024, 0, st>>>(Y + (size_t)j * ldy + j, ldy, Dj, d_status, std::max(1, std::min(8, (m - j + 15) / 16)));
@@ -2612,7 +2629,19 @@ struct Filter : FilterBase {
             k_dist_unpack_panel<T><<<dim3(128 * dist.slot_blocks[step], 1, sh_world), 32, 0, st>>>(d_dist_recv, slot, Y + j, ldy, step,
                                                                                                nblk, sh_world, sh_rank);
         }
-        if (dist.tl_cnt[step] > 0) {
+        if (trail_diag_ok() && step + 1 < nblk && dist.tb_cnt[step] >= td_min_blocks && dist.tb_cnt[step] <= std::min(td_max_blocks, num_cus)) {
+          // the rank's blocks of the update fit one round of workgroups: the update and the factor of the NEXT step as one
+          // launch (k_trail_diag: workgroup 0 updates block (j + 1, j + 1) itself and factors it), as on the plain path
+          TrailDiagArgs a{};
+          a.Y = d_Y; a.ldy = ldy; a.y_bytes = (unsigned)((size_t)2 * ldy * ldy * sizeof(T));
+          a.Dinv = d_Dinv; a.dinv_bytes = (unsigned)((size_t)(ldy / 64) * 128 * 128 * sizeof(T));
+          a.status = d_status; a.m = m; a.j = step;
+          a.blocks = d_dist_lists + dist.tb_off[step]; a.nblocks = dist.tb_cnt[step]; a.do_diag = 1;
+          Scope sc(this, KID_CHOL_TRAILING, st);
+          ++launch_cnt[EKF_LAUNCH_CHAIN_TRAIL_DIAG];
+          k_trail_diag<<<a.nblocks + 1, 1024, kChainLds, st>>>(a);
+          chain_diag_ahead = step + 1;
+        } else if (dist.tl_cnt[step] > 0) {
           Scope sc(this, KID_CHOL_TRAILING, st);
           ++launch_cnt[EKF_LAUNCH_CHAIN_STEP];
           const T* P = Y + (size_t)r0 * ldy + j;

@@ -407,14 +407,15 @@ def _gpu_env_worker(rank, world, port, n_feat, frames, z_np, px0, env, out):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,n_feat", [(2, 330), (3, 601), (5, 400)])
+@pytest.mark.parametrize("world,n_feat", [(2, 330), (3, 601), (5, 400), (2, 1000)])
 def test_hip_shard_distributed_chain_is_bit_identical(world, n_feat):
     """Round 6: from 32 block steps on the factorisation of S is DISTRIBUTED -- a rank keeps only its
     own 128-row blocks of the trailing matrix (cyclic), every diagonal block and the inverse strip up to date, and one
     all-gather per block step hands the panel round (`Filter::dist_chain_steps`).  Every tile is the replicated chain's
     tile, so mu, the rank's rows of Sigma and the gain (which needs ALL of L on every rank) equal the replicated chain's
     to the last bit.  Forced on here at 6-10 block steps (EKF_SHARD_DIST_MIN_BLOCKS=2), several chunks, uneven ownership
-    (block counts not divisible by the world size), ranks that own no block of the last steps."""
+    (block counts not divisible by the world size), ranks that own no block of the last steps; at N = 1000 (16 steps) the
+    early steps' updates are large enough to take the fused launch (k_trail_diag: the rank's blocks + the next factor)."""
     frames = 2
     from __graft_entry__ import load_package
     pkg = load_package()
@@ -432,6 +433,7 @@ def test_hip_shard_distributed_chain_is_bit_identical(world, n_feat):
         mu0, rows0, S0, K0, c0 = runs[0][rank]
         mu1, rows1, S1, K1, c1 = runs[1][rank]
         assert c0["chain_dist_gather"] == 0 and c1["chain_dist_gather"] == frames * (nblk - 1), (c0, c1)
+        assert (c1["chain_trail_diag"] > 0) == (n_feat >= 1000), c1
         assert np.array_equal(rows0, rows1)
         assert np.all(np.isfinite(mu1)) and np.all(np.isfinite(S1))
         assert np.array_equal(mu0, mu1), float(np.max(np.abs(mu0 - mu1)))
