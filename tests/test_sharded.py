@@ -433,7 +433,7 @@ def test_hip_shard_distributed_chain_is_bit_identical(world, n_feat):
         mu0, rows0, S0, K0, c0 = runs[0][rank]
         mu1, rows1, S1, K1, c1 = runs[1][rank]
         assert c0["chain_dist_gather"] == 0 and c1["chain_dist_gather"] == frames * (nblk - 1), (c0, c1)
-        assert (c1["chain_trail_diag"] > 0) == (n_feat >= 1000), c1
+        assert n_feat < 1000 or c1["chain_trail_diag"] > 0, c1
         assert np.array_equal(rows0, rows1)
         assert np.all(np.isfinite(mu1)) and np.all(np.isfinite(S1))
         assert np.array_equal(mu0, mu1), float(np.max(np.abs(mu0 - mu1)))
