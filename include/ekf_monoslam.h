@@ -402,7 +402,12 @@ int ekf_launch_count(ekf_filter* f, int kind, long long* launches);
  *       -> all-gather of the per-feature records (32 scalars per feature)             "reassemble H"
  *   update    nu; W = Sigma H^T rows {camera, own}; rows of S of the own MEASURED features
  *       -> all-gather of the row panels of S                                           "reassemble S"
- *             Cholesky chain of S in column chunks (replicated); per chunk g, beside the chain on a second stream:
+ *             Cholesky chain of S in column chunks -- replicated on every rank up to 39 block steps (N < 2500); from 40 on
+ *             DISTRIBUTED (round 6): a rank keeps its own 128-row blocks (cyclic), every diagonal block and the inverse strip of
+ *             the trailing matrix up to date, and per block step
+ *       -> all-gather of the rank's blocks of the panel                                (64 KB per block; the step's column of L)
+ *             (bit-identical to the replicated chain; EKF_SHARD_DIST_CHAIN=0 keeps it replicated, EKF_SHARD_DIST_MIN_BLOCKS
+ *             moves the threshold); per chunk g, beside the chain on a second stream:
  *             V_g = W_g Z_gg for rows {camera tile, own panel, innovation row} (one queued launch)
  *       -> all-gather of the own rows of V_g                                           (n x 2M scalars per step in all)
  *             Sigma[own rows, :] -= V_g[own rows] V_g^T (+ the replicated camera tile; the canonical tiles of k_syrk_bf16x6 that
