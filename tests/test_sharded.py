@@ -672,16 +672,21 @@ def test_hip_shard_image_side_three_ranks_match_plain_filter():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
-def test_rccl_smoke_script_rehearsal_over_gloo(world):
+@pytest.mark.parametrize("world,dist_chain", [(2, False), (3, False), (3, True)])
+def test_rccl_smoke_script_rehearsal_over_gloo(world, dist_chain):
     """tools/rccl_smoke.py -- the one-command check a multi-GPU node runs over RCCL -- rehearsed here with `world` ranks
     sharing the GPU (gloo): N = 200 (ten 128-row tiles: the ranks' panels do NOT span the matrix), all-measured and
     subset + plane updates, a removal / addition, a conversion pass that shrinks n (zero padding checked on the device),
     the two-stage update; every rank against the plain path, fp64 to 1e-8 and fp32 to 5e-3.  Regression test of the
-    round-3 finding: a converted feature's 3 x 3 cross blocks read the MIRROR feature's rows, which another rank owns."""
+    round-3 finding: a converted feature's 3 x 3 cross blocks read the MIRROR feature's rows, which another rank owns.
+    dist_chain (round 6): the same flow with the DISTRIBUTED chain forced on at this size (EKF_SHARD_DIST_MIN_BLOCKS=2: every
+    update of two block steps or more -- all-measured, subset + plane, both stages of the two-stage update -- hands its panels
+    round by all-gathers)."""
     import subprocess
     env = dict(os.environ)
     env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    if dist_chain:
+        env["EKF_SHARD_DIST_MIN_BLOCKS"] = "2"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                         "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
                         os.path.join(ROOT, "tools", "rccl_smoke.py"), "--backend", "gloo"],

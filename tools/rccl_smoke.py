@@ -13,7 +13,9 @@ replicated state: in fp64 (bound 1e-8: the protocol is exact up to the order of 
 paths may cut S into different column chunks, and an fp32 filter amplifies rounding differences of 1e-7 to 1e-4 .. 1e-3
 within a few frames, tools/shard_cadence_probe.py).  The maximum error over the ranks is all-reduced; the exit code is
 non-zero on a mismatch (or on any exception in any rank).
---backend gloo rehearses the same script with several ranks sharing ONE GPU (collectives through host memory)."""
+--backend gloo rehearses the same script with several ranks sharing ONE GPU (collectives through host memory).
+The distributed Cholesky chain (round 6) starts at 40 block steps (N >= 2500): `--features 4000`, or EKF_SHARD_DIST_MIN_BLOCKS=2 in
+the environment to put this script's small map through it."""
 import argparse
 import os
 import sys
