@@ -63,6 +63,7 @@ class TorchAllGather:
         self.backend = dist.get_backend() if dist.is_initialized() else "none"
         self._views = {}
         self._streams = {}
+        self._groups = {}                       # nccl: one process group (= one communicator) per library stream
         self.calls = 0
         self.bytes_sent = 0
         self.seconds = 0.0                      # host time inside the callback (gloo: the whole exchange)
@@ -90,9 +91,16 @@ class TorchAllGather:
                 st = torch.cuda.ExternalStream(stream, device=f"cuda:{self.device_index}") if stream else \
                     torch.cuda.default_stream(self.device_index)
                 self._streams[stream] = st
+            if stream not in self._groups:
+                # The library gathers on two streams at once (main stream: H, S and -- round 6 -- the panels of the
+                # distributed chain; gather stream: the rows of V_g).  Collectives of ONE communicator run in issue order,
+                # which would make the chain's next panel wait for the solve + gather of the chunk before; a communicator per
+                # stream keeps the two sequences independent.  Every rank meets a new stream at the same call, so the
+                # (collective) creation of the group is in step.
+                self._groups[stream] = None if (not self._groups or self.backend != "nccl") else dist.new_group(backend="nccl")
             with torch.cuda.stream(st):
                 if self.backend == "nccl":
-                    dist.all_gather_into_tensor(recv, send)
+                    dist.all_gather_into_tensor(recv, send, group=self._groups[stream])
                 else:
                     host = send.cpu()
                     parts = [torch.empty_like(host) for _ in range(self.world)]
