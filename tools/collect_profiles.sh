@@ -64,6 +64,8 @@ python3 "$R/tools/n200_error_source.py" 2>/dev/null | tail -4 > "$O/${P}_n200_er
 echo "sharded step on one rank over RCCL (world 1, forced collectives), plain row panel vs symmetric own block"
 for sym in 0 1; do EKF_SHARD_SYM=$sym python3 "$R/tools/shard_world1.py" 1000 60 2>/dev/null | tail -1 > "$O/${P}_shard_world1_nccl_sym$sym.json"; done
 python3 "$R/tools/shard_world1.py" 4000 12 2>/dev/null | tail -1 > "$O/${P}_shard_world1_nccl_n4000.json"
+EKF_SHARD_DIST_CHAIN=0 python3 "$R/tools/shard_world1.py" 4000 12 2>/dev/null | tail -1 > "$O/${P}_shard_world1_nccl_n4000_replicated_chain.json"
+EKF_SHARD_DIST_CHAIN=0 EKF_TD_MAX_BLOCKS=256 python3 "$R/tools/shard_world1.py" 4000 12 2>/dev/null | tail -1 > "$O/${P}_shard_world1_nccl_n4000_tdmax256.json"
 echo "rccl_smoke rehearsal (gloo, 2 / 3 / 4 ranks on the one GPU)"
 : > "$O/${P}_rccl_smoke_gloo.txt"
 for g in 2 3 4; do python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $g --master-addr 127.0.0.1 --master-port 2954$g "$R/tools/rccl_smoke.py" --backend gloo 2>&1 | grep "rccl_smoke" >> "$O/${P}_rccl_smoke_gloo.txt"; done
