@@ -2597,8 +2597,8 @@ struct Filter : FilterBase {
     HIPCHK(hipMemsetAsync(d_dist_counters, 0, (size_t)nblk * 8 * sizeof(int), stream));
     return EKF_OK;
   }
-  // block steps [step0, step1) of the distributed chain on stream st (no deferral, no fused launches: a step ends with its
-  // trailing update)
+  // block steps [step0, step1) of the distributed chain on stream st (no deferral: a step ends with its trailing update,
+  // which carries the factor of the next step when the rank's blocks fit one round of workgroups)
   int dist_chain_steps(int step0, int step1, int m, int m_pad, hipStream_t st) {
     if constexpr (kIsF32) {
       T* Y = d_Y;

@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(1024, 1) k_update_small_onelaunch(SmallUpdateA
   __shared__ __attribute__((aligned(16))) float sy[NB];
   __shared__ float sq[4], sJ[16], sqold[4];
   __shared__ unsigned long long sstamp[16];
-  float* const a = big;                          // staging of Sigma rows, then the factor's image, then L^-1 (`sl`), then the tile image
+  float* const a = big;                          // staging of Sigma rows, then S -> the factor's image (L below, Z = L^-T above the diagonal), then the tile image
   float* const sVi = big + NB * LDA;             // V_i | V_j, 64 x 132 each
   float* const sVj = sVi + 64 * PITCH;
 
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(1024, 1) k_update_small_onelaunch(SmallUpdateA
     if (t < 4) sqold[t] = g.mu[3 + t];
   }
 
-  // ---- W = Sigma H^T into the image, 64 rows of Sigma at a time through `a` (k_sigma_ht's sums) -------------------------
+  // ---- W = Sigma H^T into the image, RC rows of Sigma at a time through `a` (k_sigma_ht's sums) -------------------------
   EKF_SMALL_STAMP(1);
   const int SP = 4 * nq;                         // pitch of the staged rows (a 3-entry feature at the end of a row reads on into
                                                  // the next row's first words, or the four zero words behind the last one: unused, finite)
