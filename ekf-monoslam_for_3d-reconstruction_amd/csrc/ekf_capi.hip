@@ -922,7 +922,7 @@ struct Filter : FilterBase {
     const int dst = 1 - cur, dmu = 1 - cur_mu;
     {
       Scope sc(this, KID_COMPACT);
-      dim3 grid(std::min((n_new + 1023) / 1024, 8), n_new);    // four columns per lane (k_compact_transform)
+      dim3 grid((n_new + 1023) / 1024, (n_new + kCompactRows - 1) / kCompactRows);   // four columns per lane, kCompactRows rows per workgroup
       k_compact_transform<T><<<grid, 256, 0, stream>>>(S(), d_S[dst], ld, n_new, d_map_src, d_map_conv, d_Jy);
       k_compact_mu<T><<<(n_new + 255) / 256, 256, 0, stream>>>(mu(), d_mu[dmu], n_new, d_map_src, d_map_conv,
                                                               d_Yxyz);

@@ -639,67 +639,97 @@ __global__ void k_add_border(T* __restrict__ S, int ld, int n, const T* __restri
 // pass-through, else (converted feature slot * 3 + component e): the new entry is
 // sum_b Jy[slot][e][b] * old[src + b], b < 6.  Lanes sweep j' (coalesced), blockIdx.y = i'.
 // ---------------------------------------------------------------------------------------
+constexpr int kCompactRows = 32;                 // rows of the new matrix per workgroup of k_compact_transform
 template <typename T>
 __global__ void k_compact_transform(const T* __restrict__ src, T* __restrict__ dst, int ld,
                                     int n_new, const int* __restrict__ map_src,
                                     const int* __restrict__ map_conv, const T* __restrict__ Jy) {
-  const int ip = blockIdx.y;
-  const int si0 = map_src[ip];
-  const int ci0 = map_conv[ip];
   // Round 5: a lane takes FOUR consecutive output columns.  Where they are a pass-through run of the source row (the common
   // case: a removal deletes 6 or 3 columns here and there, everything between them is a shifted copy) the lane moves 16
   // bytes per instruction -- a dword-aligned 16-byte load (the shift is a multiple of 3 floats), a 16-byte aligned store --
-  // instead of four 4-byte round trips: the pass is an HBM stream (2 n^2 s), and at one dword per lane it ran at 0.29 of
-  // the HBM peak (N = 4000: 2.0 ms per removal).  Everything else takes the element path below.
+  // instead of four 4-byte round trips: the pass is an HBM stream (2 n^2 s).
+  // Round 6: the column descriptors of a lane do not depend on the row, so a workgroup keeps its 1024 columns and walks
+  // kCompactRows rows with them -- one load and one store per 16 bytes moved where round 5 issued two descriptor loads
+  // beside them (0.37-0.39 of the HBM peak, bound by load issue) --, four rows in flight per lane.
   typedef T vec4u __attribute__((ext_vector_type(4), aligned(sizeof(T))));
   typedef T vec4a __attribute__((ext_vector_type(4)));
   typedef int int4a __attribute__((ext_vector_type(4)));
-  for (int jq = (blockIdx.x * blockDim.x + threadIdx.x) * 4; jq < n_new; jq += gridDim.x * blockDim.x * 4) {
-    if (ci0 < 0 && jq + 3 < n_new) {
-      const int4a ms = *reinterpret_cast<const int4a*>(map_src + jq);
-      const int4a mc = *reinterpret_cast<const int4a*>(map_conv + jq);
-      if ((mc[0] & mc[1] & mc[2] & mc[3]) < 0 && ms[3] - ms[0] == 3) {
-        const vec4u v = *reinterpret_cast<const vec4u*>(src + (size_t)si0 * ld + ms[0]);
+  const int jq = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int row0 = blockIdx.y * kCompactRows, row1 = min(row0 + kCompactRows, n_new);
+  bool run = false;                               // the lane's four columns are a pass-through run of the source row
+  int ms0 = 0;
+  if (jq + 3 < n_new) {
+    const int4a ms = *reinterpret_cast<const int4a*>(map_src + jq);
+    const int4a mc = *reinterpret_cast<const int4a*>(map_conv + jq);
+    run = (mc[0] & mc[1] & mc[2] & mc[3]) < 0 && ms[3] - ms[0] == 3;
+    ms0 = ms[0];
+  }
+  for (int ipb = row0; ipb < row1; ipb += 8) {
+    int si[8], ci[8];
+    bool plain = true;                            // (uniform) none of the four rows is a converted entry
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int ip = min(ipb + u, n_new - 1);
+      si[u] = map_src[ip];
+      ci[u] = map_conv[ip];
+      plain = plain && ci[u] < 0;
+    }
+    if (jq >= n_new) continue;
+    if (run && plain) {
+      vec4u v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const vec4u*>(src + (size_t)si[u] * ld + ms0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (ipb + u < row1) *reinterpret_cast<vec4a*>(dst + (size_t)(ipb + u) * ld + jq) = vec4a{v[u][0], v[u][1], v[u][2], v[u][3]};
+      continue;
+    }
+#pragma unroll 1
+    for (int u = 0; u < 8; ++u) {
+      const int ip = ipb + u;
+      if (ip >= row1) break;
+      const int si0 = si[u], ci0 = ci[u];
+      if (run && ci0 < 0) {
+        const vec4u v = *reinterpret_cast<const vec4u*>(src + (size_t)si0 * ld + ms0);
         *reinterpret_cast<vec4a*>(dst + (size_t)ip * ld + jq) = vec4a{v[0], v[1], v[2], v[3]};
         continue;
       }
-    }
 #pragma unroll 1
-    for (int jp = jq; jp < min(jq + 4, n_new); ++jp) {
-    const int si = si0, ci = ci0;
-    const int sj = map_src[jp];
-    const int cj = map_conv[jp];
-    T acc;
-    if (ci < 0 && cj < 0) {
-      acc = src[(size_t)si * ld + sj];
-    } else if (ci < 0) {
-      acc = T(0);
-      for (int b = 0; b < 6; ++b) acc = t_fma(src[(size_t)si * ld + sj + b], Jy[cj * 6 + b], acc);
-    } else if (cj < 0) {
-      acc = T(0);
-      for (int a = 0; a < 6; ++a) acc = t_fma(Jy[ci * 6 + a], src[(size_t)(si + a) * ld + sj], acc);
-    } else if (jp <= ip) {
-      // 3 x 3 block of two converted entries, lower triangle: sum_a Jy_i[a] (sum_b S[i+a][j+b] Jy_j[b])
-      acc = T(0);
-      for (int a = 0; a < 6; ++a) {
-        T inner = T(0);
-        for (int b = 0; b < 6; ++b) inner += src[(size_t)(si + a) * ld + sj + b] * Jy[cj * 6 + b];
-        acc += Jy[ci * 6 + a] * inner;
+      for (int jp = jq; jp < min(jq + 4, n_new); ++jp) {
+        const int sj = map_src[jp];
+        const int cj = map_conv[jp];
+        T acc;
+        if (ci0 < 0 && cj < 0) {
+          acc = src[(size_t)si0 * ld + sj];
+        } else if (ci0 < 0) {
+          acc = T(0);
+          for (int b = 0; b < 6; ++b) acc = t_fma(src[(size_t)si0 * ld + sj + b], Jy[cj * 6 + b], acc);
+        } else if (cj < 0) {
+          acc = T(0);
+          for (int a = 0; a < 6; ++a) acc = t_fma(Jy[ci0 * 6 + a], src[(size_t)(si0 + a) * ld + sj], acc);
+        } else if (jp <= ip) {
+          // 3 x 3 block of two converted entries, lower triangle: sum_a Jy_i[a] (sum_b S[i+a][j+b] Jy_j[b])
+          acc = T(0);
+          for (int a = 0; a < 6; ++a) {
+            T inner = T(0);
+            for (int b = 0; b < 6; ++b) inner += src[(size_t)(si0 + a) * ld + sj + b] * Jy[cj * 6 + b];
+            acc += Jy[ci0 * 6 + a] * inner;
+          }
+        } else {
+          // ... upper triangle: Jy (S Jy^T) is symmetric only up to rounding, so the element is evaluated in the ORDER of its
+          // mirror element -- sum_b Jy_j[b] (sum_a S[i+a][j+b] Jy_i[a]), on an exactly symmetric source the same products in
+          // the same sequence -- but from the rows of THIS entry's feature: exactly symmetric, and under row-panel sharding
+          // only rows the rank owns are read (round 2 swapped the roles and read the mirror feature's rows, which another
+          // rank may own: found by tools/rccl_smoke.py in round 3)
+          acc = T(0);
+          for (int b = 0; b < 6; ++b) {
+            T inner = T(0);
+            for (int a = 0; a < 6; ++a) inner += src[(size_t)(si0 + a) * ld + sj + b] * Jy[ci0 * 6 + a];
+            acc += Jy[cj * 6 + b] * inner;
+          }
+        }
+        dst[(size_t)ip * ld + jp] = acc;
       }
-    } else {
-      // ... upper triangle: Jy (S Jy^T) is symmetric only up to rounding, so the element is evaluated in the ORDER of its
-      // mirror element -- sum_b Jy_j[b] (sum_a S[i+a][j+b] Jy_i[a]), on an exactly symmetric source the same products in
-      // the same sequence -- but from the rows of THIS entry's feature: exactly symmetric, and under row-panel sharding
-      // only rows the rank owns are read (round 2 swapped the roles and read the mirror feature's rows, which another
-      // rank may own: found by tools/rccl_smoke.py in round 3)
-      acc = T(0);
-      for (int b = 0; b < 6; ++b) {
-        T inner = T(0);
-        for (int a = 0; a < 6; ++a) inner += src[(size_t)(si + a) * ld + sj + b] * Jy[ci * 6 + a];
-        acc += Jy[cj * 6 + b] * inner;
-      }
-    }
-    dst[(size_t)ip * ld + jp] = acc;
     }
   }
 }
