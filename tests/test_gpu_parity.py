@@ -1038,6 +1038,51 @@ def test_small_map_onelaunch_update_is_bit_identical(monkeypatch, n_feat, stride
             assert np.array_equal(a0, a1), (k, name, float(np.max(np.abs(a0.astype(np.float64) - a1))))
 
 
+@pytest.mark.parametrize("n_feat", [32, 200])
+def test_update_device_equals_host_list_and_flags_bad_lists(n_feat):
+    """`ekf_update_device` (z and the list resident on the device: what bench.py times) against `ekf_update` on the same inputs,
+    bit for bit -- on the one-launch path of small maps (N = 32) and on the chunk path (N = 200) -- and the one check a resident
+    list cannot get on the host: an index outside [0, N) or a list that is not strictly ascending raises the status word on the
+    device (every kernel clamps what it reads meanwhile), and the next synchronising call returns EKF_ERR_ARG."""
+    import torch
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from ekf_monoslam_amd import synthetic
+    cfg = pkg.kinect_config()
+    frames = 3
+    px0, z = synthetic.measurement_stream(cfg, n_feat, frames, sigma_px=0.5)
+    idx = np.arange(0, n_feat, 2, dtype=np.int32)
+    d_idx = torch.from_numpy(idx).cuda()
+    outs = []
+    for resident in (False, True):
+        f = pkg.VSlamFilter(cfg, capacity_features=n_feat)
+        f.setDt(1.0 / 30.0)
+        for (u, v) in px0:
+            assert f.addFeature((u, v)) == 1
+        for k in range(frames):
+            f.predict()
+            zk = np.ascontiguousarray(z[k][idx].reshape(-1), np.float32)
+            if resident:
+                d_z = torch.from_numpy(zk).cuda()
+                f.update_device(d_z.data_ptr(), d_idx.data_ptr(), len(idx), True)
+                f.synchronize()
+            else:
+                f.update(zk, idx, plane_constraint=True)
+        outs.append((f.getFullState(), f.getFullSigma()))
+        if resident:
+            for bad in (np.r_[idx[:-1], n_feat + 5].astype(np.int32), idx[::-1].copy()):
+                f.predict()
+                d_bad = torch.from_numpy(bad).cuda()
+                d_z = torch.from_numpy(np.ascontiguousarray(z[0][idx].reshape(-1), np.float32)).cuda()
+                with pytest.raises(pkg.EkfError) as e:
+                    f.update_device(d_z.data_ptr(), d_bad.data_ptr(), len(bad), False)
+                    f.synchronize()
+                    f.getFullState()
+                assert e.value.status == 1 and "device-resident index" in str(e.value), str(e.value)
+        f.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_chunk_plan_knob_changes_rounding_only(monkeypatch):
     """EKF_CHUNKS (where the column chunks of the factorisation end) is NOT a bit-identity knob: another plan is another
     order of the sequential form (which columns of W are re-evaluated from which downdated Sigma).  Same update up to fp32
