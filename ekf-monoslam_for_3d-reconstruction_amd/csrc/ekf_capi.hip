@@ -18,6 +18,7 @@
 #include "ekf_syrk6.hpp"
 #include "ekf_chain.hpp"
 #include "ekf_small.hpp"
+#include "ekf_step.hpp"
 #include "ekf_kernels.hpp"
 #include "ekf_shard.hpp"
 
@@ -64,7 +65,7 @@ static const char* kLaunchNames[EKF_LAUNCH_KINDS] = {
     "downdate_bf16x6", "downdate_f32", "downdate_f32_fused_wu", "downdate_f32_half_tail", "downdate_f32_t64",
     "row_rider", "row_gemv", "row_tile_gemm", "w_update_gemm", "w_recompute",
     "chain_step_launches", "chain_persistent", "solve", "solve_two_groups", "update_oneblock", "update_allinone",
-    "chain_trail_diag", "split_image", "state_update_tail", "update_onelaunch", "chain_dist_gather"};
+    "chain_trail_diag", "split_image", "state_update_tail", "update_onelaunch", "chain_dist_gather", "chain_step_fused"};
 
 static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
@@ -231,6 +232,12 @@ struct Filter : FilterBase {
   // the whole update of a small map (n_pad <= 256, one diagonal block) as ONE launch (k_update_small_onelaunch, ekf_small.hpp);
   // EKF_SMALL_ONELAUNCH=0: W, S, the factor and the rest as four launches (rounds 3-5; A/B and bit-identity check)
   int opt_small_onelaunch = 1;
+  // a block step of the chain (factor, panel, trailing update) as ONE launch where the step has fewer workgroups than the chip has
+  // CUs and the chain runs alone (one column chunk: N up to ~230; k_chain_step_fused, ekf_step.hpp); EKF_STEP_FUSED=0: three launches
+  int opt_step_fused = 1;
+  struct StepPlan { int nblk = 0, s1 = 0; std::vector<int> off, cnt; } sfp;
+  int* d_sf_lists = nullptr;
+  bool sf_now = false;                                  // this update's chain may take the fused step (set by update())
   unsigned long long* d_small_stamps = nullptr;         // EKF_SMALL_STAMPS=1: phase stamps of its workgroup 0 (ekf_peek_workspace, which = 3)
   unsigned small_gate_total = 0;                        // arrivals the gate word (d_status[9]) has seen when every launch so far is over
   int opt_su_tail = 1;                                  // EKF_SU_TAIL=0: k_state_update as its own launch on the second stream beside the last downdate (round 5)
@@ -306,7 +313,7 @@ struct Filter : FilterBase {
                     d_frame, d_patch[0], d_patch[1], d_mpatch[0], d_mpatch[1], d_hb, d_zm, d_found, d_score, d_keep,
                     d_Vimg, d_stage_send, d_stage_recv, d_archive, d_arch_idx, d_panel_tiles, d_shard_solve, d_shard_syrk,
                     d_chain_tasks, d_chain_flags, d_chain_trace, d_td_blocks, d_small_stamps,
-                    d_dist_lists, d_dist_counters, d_dist_send, d_dist_recv};
+                    d_dist_lists, d_dist_counters, d_dist_send, d_dist_recv, d_sf_lists};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int s = 0; s < kInSlots; ++s) { if (h_in[s]) hipHostFree(h_in[s]); if (ev_in[s]) hipEventDestroy(ev_in[s]); }
     if (h_pred) hipHostFree(h_pred);
@@ -467,6 +474,7 @@ struct Filter : FilterBase {
       if (const char* e = getenv("EKF_FUSE_SPLIT")) opt_fuse_split = atoi(e) ? 1 : 0;
       if (const char* e = getenv("EKF_SU_TAIL")) opt_su_tail = atoi(e) ? 1 : 0;
       if (const char* e = getenv("EKF_SMALL_ONELAUNCH")) opt_small_onelaunch = atoi(e) ? 1 : 0;
+      if (const char* e = getenv("EKF_STEP_FUSED")) opt_step_fused = atoi(e) ? 1 : 0;
       if (const char* e = getenv("EKF_SHARD_DIST_CHAIN")) opt_shard_dist_chain = atoi(e) ? 1 : 0;
       if (const char* e = getenv("EKF_SHARD_DIST_MIN_BLOCKS")) shard_dist_min_blocks = std::max(2, atoi(e));
       if (const char* e = getenv("EKF_SMALL_STAMPS")) {
@@ -1513,6 +1521,52 @@ struct Filter : FilterBase {
   // `defer_last`: the trailing update of the chunk's LAST step is left to the next call (it only touches columns >= c1, so
   // the chunk -- its columns of L and its strip -- is complete without it, and the caller records the chunk's event one
   // launch earlier: the second stream starts on the chunk while this update is still running)
+  // ---- a whole block step as one launch (ekf_step.hpp): the work lists of a ONE-chunk plan of nblk steps -------------------
+  int ensure_step_fused_lists(int nblk) {
+    if (sfp.nblk == nblk) return EKF_OK;
+    std::vector<int> all;
+    sfp.off.assign(nblk, 0);
+    sfp.cnt.assign(nblk, 0);
+    const int s0 = 0, s1 = nblk;
+    for (int j = 0; j < nblk; ++j) {
+      sfp.off[j] = (int)all.size();
+      const int first = 2 * (j + 1);                        // first 64-row / 64-column block of the trailing matrix
+      for (int r = first; r < 2 * nblk; ++r)                // S rows below the diagonal block: lower tiles, the diagonal one writes the panel rows
+        for (int c = first; c <= r; ++c) { all.push_back(r); all.push_back(c); all.push_back(SF_TILE | (c == r ? SF_WRITE_PANEL : 0)); }
+      for (int r = 2 * nblk; r < 2 * nblk + 2 * (j + 1 - s0); ++r) {   // the strip rows of the chunk: columns up to its end
+        if (first < 2 * s1) {
+          for (int c = first; c < 2 * s1; ++c) { all.push_back(r); all.push_back(c); all.push_back(SF_TILE | (c == first ? SF_WRITE_PANEL : 0)); }
+        } else {
+          all.push_back(r); all.push_back(r); all.push_back(SF_WRITE_PANEL);           // no tile: the panel rows only
+        }
+      }
+      sfp.cnt[j] = ((int)all.size() - sfp.off[j]) / 3;
+      all[sfp.off[j] + 2] |= SF_WRITE_DIAG;                 // (a step always has a workgroup: the strip rows)
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    if (d_sf_lists) HIPCHK(hipFree(d_sf_lists));
+    d_sf_lists = nullptr;
+    HIPCHK(hipMalloc(&d_sf_lists, all.size() * sizeof(int)));
+    HIPCHK(hipMemcpy(d_sf_lists, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice));
+    sfp.nblk = nblk; sfp.s1 = s1;
+    return EKF_OK;
+  }
+  bool launch_step_fused(int step, int m, hipStream_t sc_) {
+    if constexpr (kIsF32) {
+      if (!sf_now || sfp.nblk == 0 || step >= sfp.nblk || sfp.cnt[step] > num_cus / 2 || sc_ != stream) return false;   // (every workgroup resident, with room to spare)
+      StepFusedArgs a{};
+      a.Y = d_Y; a.ldy = ldy; a.Dj = d_Dinv + (size_t)step * 128 * 128; a.status = d_status; a.m = m; a.j = step;
+      a.wl = d_sf_lists + sfp.off[step]; a.nwg = sfp.cnt[step];
+      a.gate = reinterpret_cast<unsigned*>(d_status + 9);
+      small_gate_total += (unsigned)a.nwg;
+      a.gate_target = small_gate_total;
+      Scope sc(this, KID_CHOL_TRAILING, sc_);
+      ++launch_cnt[EKF_LAUNCH_CHAIN_STEP_FUSED];
+      k_chain_step_fused<<<a.nwg, 1024, 0, sc_>>>(a);
+      return true;
+    }
+    return false;
+  }
   struct PendingTrailing { int step = -1, c0 = 0, c1 = 0; } chain_pending;
   void chain_trailing(int step, int c0, int c1, int m, int m_pad, hipStream_t sc_, bool allow_fused) {
     const int nb = NB();
@@ -1537,6 +1591,7 @@ struct Filter : FilterBase {
       chain_pending.step = -1;
     }
     for (int step = step0; step < step1; ++step) {
+      if (!skip_panel && !defer_last && chain_diag_ahead != step && launch_step_fused(step, m, sc_)) continue;
       const int j = step * nb;
       T* Ajj = Y + (size_t)j * ldy + j;
       T* Dj = d_Dinv + (size_t)step * nb * nb;
@@ -1700,6 +1755,15 @@ struct Filter : FilterBase {
     chain_pending.step = -1;
     td_nblk = (td_nblk == nsteps) ? td_nblk : 0;
     if (!pchain && !oneblock && trail_diag_ok() && nb == 128 && nsteps >= 2) { rc = ensure_trail_diag_lists(nsteps, nchunks, cend); if (rc) return rc; }
+    sf_now = false;
+    if constexpr (kIsF32) {
+      if (opt_step_fused && opt_mfma && opt_fused && nb == 128 && nchunks == 1 && !oneblock && !pchain && !prof_on(KID_CHOL_DIAG) &&
+          !prof_on(KID_CHOL_PANEL) && !prof_on(KID_CHOL_TRAILING)) {
+        rc = ensure_step_fused_lists(nsteps);
+        if (rc) return rc;
+        sf_now = true;
+      }
+    }
     if (onelaunch) allinone = true;
     for (int gi = 0; gi < (onelaunch ? 0 : nchunks); ++gi) {
       const int c0 = step * nb, c1 = cend[gi] * nb;
@@ -3382,6 +3446,7 @@ struct Filter : FilterBase {
     if constexpr (kIsF32) sh_rec = opt_mfma && opt_wrecompute && nb == 128 && nchunks > 1;
     int step = 0;
     bool side_busy = false;
+    sf_now = false;                                        // (the fused block step is the plain path's)
     const bool dchain = dist_chain_ok(nsteps);             // the factorisation distributed over the ranks (see dist_chain_steps)
     const bool pchain = !dchain && chain_persistent_ok() && nb == 128 && nsteps >= 2;
     if (pchain) { rc = chain_begin_update(nsteps, nchunks, cend); if (rc) return rc; }

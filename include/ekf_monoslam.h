@@ -388,6 +388,7 @@ enum ekf_launch_kind {
   EKF_LAUNCH_STATE_UPDATE_TAIL,       /* mu += V y done by the workgroups of the last k_syrk_bf16x6 launch that run out of tiles */
   EKF_LAUNCH_UPDATE_ONELAUNCH,        /* k_update_small_onelaunch: W, S, the factor and the whole rest of the update of a small map (n_pad <= 256) as ONE launch (round 6) */
   EKF_LAUNCH_CHAIN_DIST_GATHER,       /* sharded step, distributed chain: all-gathers of a block step's panel (round 6) */
+  EKF_LAUNCH_CHAIN_STEP_FUSED,        /* k_chain_step_fused: factor, panel and trailing update of a block step as ONE launch (one-chunk maps, round 6) */
   EKF_LAUNCH_KINDS
 };
 int ekf_launch_kinds(void);

@@ -1083,6 +1083,46 @@ def test_update_device_equals_host_list_and_flags_bad_lists(n_feat):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("n_feat,stride,plane", [(70, 1, True), (200, 1, False), (200, 3, True), (230, 1, True)])
+def test_fused_block_step_is_bit_identical(monkeypatch, n_feat, stride, plane):
+    """Round 6: on maps whose chain is one column chunk (up to ~230 features: BASELINE configs[1]) a block step of the Cholesky
+    chain -- diagonal factor, panel, trailing update -- is ONE launch (k_chain_step_fused: every tile workgroup factors the
+    diagonal block and forms its two panel blocks for itself) instead of three.  Every sum is the sum of the launch it
+    replaces: mu, Sigma and the gain equal the three-launch chain (EKF_STEP_FUSED=0) to the last bit; the launch counters
+    prove which path ran (2 - 4 block steps per update here, measured subsets and plane rows included)."""
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from ekf_monoslam_amd import synthetic
+    cfg = pkg.kinect_config()
+    frames = 3
+    px0, z = synthetic.measurement_stream(cfg, n_feat, frames, sigma_px=0.5)
+    idx = np.arange(0, n_feat, stride, dtype=np.int32)
+    outs, counts = [], []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("EKF_STEP_FUSED", mode)
+        f = pkg.VSlamFilter(cfg, capacity_features=n_feat)
+        f.setDt(1.0 / 30.0)
+        for (u, v) in px0:
+            assert f.addFeature((u, v)) == 1
+        per = []
+        for k in range(frames):
+            f.predict()
+            f.update(z[k][idx].reshape(-1), idx, plane_constraint=plane)
+            per.append((f.getFullState(), f.getFullSigma(), f.getGain()))
+        assert f.checkInvariants()[0] == 0.0
+        outs.append(per)
+        counts.append(f.launch_counts())
+        f.close()
+    monkeypatch.delenv("EKF_STEP_FUSED", raising=False)
+    nblk = (2 * len(idx) + (3 if plane else 0) + 127) // 128
+    assert nblk >= 2
+    assert counts[0]["chain_step_fused"] == 0 and counts[1]["chain_step_fused"] == frames * nblk, (counts[0], counts[1])
+    assert counts[1]["chain_step_launches"] == 0 and counts[0]["chain_step_launches"] > 0
+    for k in range(frames):
+        for name, a0, a1 in zip(("mu", "Sigma", "gain"), outs[0][k], outs[1][k]):
+            assert np.array_equal(a0, a1), (k, name, float(np.max(np.abs(a0.astype(np.float64) - a1))))
+
+
 def test_chunk_plan_knob_changes_rounding_only(monkeypatch):
     """EKF_CHUNKS (where the column chunks of the factorisation end) is NOT a bit-identity knob: another plan is another
     order of the sequential form (which columns of W are re-evaluated from which downdated Sigma).  Same update up to fp32
