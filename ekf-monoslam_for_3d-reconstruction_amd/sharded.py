@@ -8,7 +8,8 @@ reduction anywhere: on a fully connected xGMI node every peer pair moves its pan
 
     predict                  -> per-feature records h | Hc | Hf | flags           ("reassemble H")
     update: W rows, S rows   -> row panels of S                                   ("reassemble S")
-            per column chunk of the factorisation, beside the replicated Cholesky chain:
+            per column chunk of the factorisation, beside the Cholesky chain (replicated; from 40 block steps on
+            distributed: cyclic row blocks, one all-gather of the own panel blocks per block step):
             V_g = W_g Z_gg   -> own rows of V_g                                    (n x 2M scalars per step in all)
             Sigma[own rows] -= V_g[own rows] V_g^T
     convert2XYZ_ifLinearAll  -> linearity flags (one byte per feature)
@@ -236,6 +237,7 @@ def bench(pkg, cfg, n_feat, px0, z, args, rank, world, dev):
                         "traffic": None, "avg_launch_ms": round(dd_ms / dd_cnt, 4),
                         "algorithmic_flop_per_launch": flop, "launches_per_step": dd_cnt / k}
     info = shard_info(flt)
+    dist_gathers = flt.launch_counts().get("chain_dist_gather", 0)       # (which form of the chain the library took)
     result = {
         "metric": "EKF updates/sec at N features (state dim 14+6N)",
         "value": round(args.steps / elapsed, 2), "unit": "updates/s",
@@ -251,7 +253,9 @@ def bench(pkg, cfg, n_feat, px0, z, args, rank, world, dev):
                    "features": n_feat, "state_dim": n, "measured_per_frame": n_feat,
                    "parallelism": f"row-panel shard x{world}: all-gather H, S, V over "
                                   f"{'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend() + ' (host staging, functional rehearsal)'}"
-                                  ", chunk-pipelined beside the replicated Cholesky chain",
+                                  + (", chunk-pipelined beside the DISTRIBUTED Cholesky chain (cyclic row blocks, one all-gather "
+                                     "of the panel per block step)" if dist_gathers > 0 else
+                                     ", chunk-pipelined beside the replicated Cholesky chain"),
                    "backend": dist.get_backend(),
                    "frames_per_map": seg, "maps": nseg},
         "run_sane": sane,
