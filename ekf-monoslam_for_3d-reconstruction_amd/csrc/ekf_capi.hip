@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -68,6 +69,31 @@ static const char* kLaunchNames[EKF_LAUNCH_KINDS] = {
     "chain_trail_diag", "split_image", "state_update_tail", "update_onelaunch", "chain_dist_gather", "chain_step_fused"};
 
 static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// CU-masked streams are never destroyed: hipStreamDestroy of a stream made by hipExtStreamCreateWithCUMask stalls for good about
+// once in a few hundred calls on this runtime (ROCm 7.2; tools/lifecycle_soak.py, DESIGN.md 8: the cause of the two test hangs of
+// round 6).  A filter that goes away hands its stream back -- idle: its work was synchronised -- and the next filter of the same
+// device and mask takes it over; what is left in the pool at process exit is left to the runtime.
+struct MaskedStreamPool {
+  struct Entry { int device, num_cus, reserved; hipStream_t st; };
+  std::mutex mu;
+  std::vector<Entry> idle;
+  hipStream_t take(int device, int num_cus, int reserved) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (size_t i = 0; i < idle.size(); ++i)
+      if (idle[i].device == device && idle[i].num_cus == num_cus && idle[i].reserved == reserved) {
+        hipStream_t st = idle[i].st;
+        idle.erase(idle.begin() + i);
+        return st;
+      }
+    return nullptr;
+  }
+  void give(int device, int num_cus, int reserved, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(mu);
+    idle.push_back({device, num_cus, reserved, st});
+  }
+};
+static MaskedStreamPool g_masked_streams;
 
 struct FilterBase {
   std::string err;
@@ -202,6 +228,8 @@ struct Filter : FilterBase {
   hipStream_t stream_b = nullptr;                       // solve pieces / downdate pieces, overlapped with the chain
   hipEvent_t ev_chain[8] = {}, ev_solve[8] = {}, ev_b = nullptr, ev_wu = nullptr;
   hipStream_t stream_g = nullptr;                       // sharded step: the all-gathers of V_g, beside the rank's solves
+  bool stream_b_masked = false;                         // stream_b carries a CU mask: handed back to the pool, never destroyed
+  int stream_b_reserved = 0;                            // the mask it was made with (reserved_cus may be changed later)
   hipEvent_t ev_gath[8] = {}, ev_g = nullptr;
   int solve64_off = 0, solve6464_off = 0, tri64_off = 0, tri64_count = 0;
   int tri6_off = 0;                                      // the lower-triangular list, diagonal tiles first (k_syrk_bf16x6)
@@ -303,10 +331,18 @@ struct Filter : FilterBase {
   int NB() const { return (kIsF32 && opt_mfma) ? 128 : 64; }
 
   ~Filter() override {
+    const bool dbg = getenv("EKF_DEBUG_DTOR") != nullptr;       // (diagnostics: which call of the tear-down a stall sits in)
+    auto mark = [&](const char* what) { if (dbg) { fprintf(stderr, "[ekf dtor %p] %s\n", (void*)this, what); fflush(stderr); } };
     hipSetDevice(device);
+    mark("sync main stream");
     if (stream) hipStreamSynchronize(stream);
+    mark("sync side streams");
+    if (stream_b) hipStreamSynchronize(stream_b);
+    if (stream_g) hipStreamSynchronize(stream_g);
+    mark("events");
     for (auto& p : pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : pool) hipEventDestroy(e);
+    mark("device memory");
     void* ptrs[] = {d_pos, d_coding, d_mu[0], d_mu[1], d_S[0], d_S[1], d_scr, d_h, d_Hc, d_Hf, d_Sd,
                     d_flags, d_cflag, d_Jy, d_Yxyz, d_map_src, d_map_conv, d_Y, d_W, d_V, d_Dinv, d_z, d_midx,
                     d_status, d_tmp, d_K, d_tilemap, d_counters, d_ibuf, d_rmask, d_pts, d_tab,
@@ -315,20 +351,27 @@ struct Filter : FilterBase {
                     d_chain_tasks, d_chain_flags, d_chain_trace, d_td_blocks, d_small_stamps,
                     d_dist_lists, d_dist_counters, d_dist_send, d_dist_recv, d_sf_lists};
     for (void* p : ptrs) if (p) hipFree(p);
+    mark("host memory");
     for (int s = 0; s < kInSlots; ++s) { if (h_in[s]) hipHostFree(h_in[s]); if (ev_in[s]) hipEventDestroy(ev_in[s]); }
     if (h_pred) hipHostFree(h_pred);
     if (h_ransac) hipHostFree(h_ransac);
     if (h_gate) hipHostFree(h_gate);
     if (h_rb) hipHostFree(h_rb);
+    mark("streams");
     if (own_stream && stream) hipStreamDestroy(stream);
-    if (stream_b) hipStreamDestroy(stream_b);
+    mark("stream b");
+    if (stream_b && stream_b_masked) g_masked_streams.give(device, num_cus, stream_b_reserved, stream_b);
+    else if (stream_b) hipStreamDestroy(stream_b);
+    mark("stream g");
     if (stream_g) hipStreamDestroy(stream_g);
+    mark("last events");
     for (auto e : ev_gath) if (e) hipEventDestroy(e);
     if (ev_g) hipEventDestroy(ev_g);
     for (auto e : ev_chain) if (e) hipEventDestroy(e);
     for (auto e : ev_solve) if (e) hipEventDestroy(e);
     if (ev_b) hipEventDestroy(ev_b);
     if (ev_wu) hipEventDestroy(ev_wu);
+    mark("done");
   }
 
   // ---- profiling helpers ---------------------------------------------------------------
@@ -451,12 +494,19 @@ struct Filter : FilterBase {
       std::vector<uint32_t> mask((num_cus + 31) / 32, 0xffffffffu);
       for (int i = 0; i < reserved_cus; ++i) mask[i / 32] &= ~(1u << (i % 32));
       // (a runtime that refuses CU masks still gets a second stream: the overlap works, only less well)
-      if (hipExtStreamCreateWithCUMask(&stream_b, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-        (void)hipGetLastError();
-        stream_b = nullptr;
-        reserved_cus = 0;
-        HIPCHK(hipStreamCreateWithFlags(&stream_b, hipStreamNonBlocking));
+      stream_b = g_masked_streams.take(device, num_cus, reserved_cus);      // (a masked stream is reused, never destroyed: see the pool)
+      stream_b_masked = stream_b != nullptr;
+      if (!stream_b) {
+        if (hipExtStreamCreateWithCUMask(&stream_b, (uint32_t)mask.size(), mask.data()) == hipSuccess) {
+          stream_b_masked = true;
+        } else {
+          (void)hipGetLastError();
+          stream_b = nullptr;
+          reserved_cus = 0;
+          HIPCHK(hipStreamCreateWithFlags(&stream_b, hipStreamNonBlocking));
+        }
       }
+      stream_b_reserved = reserved_cus;
 
       if (const char* e = getenv("EKF_FUSE_WU")) opt_fuse_wu = atoi(e);
       if (const char* e = getenv("EKF_ROW_GEMV")) opt_row_gemv = atoi(e) ? 1 : 0;
