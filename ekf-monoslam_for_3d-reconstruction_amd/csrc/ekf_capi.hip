@@ -73,11 +73,16 @@ static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 // CU-masked streams are never destroyed: hipStreamDestroy of a stream made by hipExtStreamCreateWithCUMask stalls for good about
 // once in a few hundred calls on this runtime (ROCm 7.2; tools/lifecycle_soak.py, DESIGN.md 8: the cause of the two test hangs of
 // round 6).  A filter that goes away hands its stream back -- idle: its work was synchronised -- and the next filter of the same
-// device and mask takes it over; what is left in the pool at process exit is left to the runtime.
+// device and mask takes it over.  What is left in the pool at process exit is destroyed by an atexit handler registered on first
+// use -- i.e. behind the runtime's own initialisation, so it runs in front of the runtime's (and a profiler's) tear-down: a masked
+// stream still alive at that point crashes rocprofv3's exit (SIGSEGV in __cxa_finalize); one destroy per process and mask, on an
+// idle device, instead of one per filter.
 struct MaskedStreamPool {
   struct Entry { int device, num_cus, reserved; hipStream_t st; };
   std::mutex mu;
   std::vector<Entry> idle;
+  bool hooked = false;
+  static void at_exit();
   hipStream_t take(int device, int num_cus, int reserved) {
     std::lock_guard<std::mutex> lk(mu);
     for (size_t i = 0; i < idle.size(); ++i)
@@ -91,9 +96,19 @@ struct MaskedStreamPool {
   void give(int device, int num_cus, int reserved, hipStream_t st) {
     std::lock_guard<std::mutex> lk(mu);
     idle.push_back({device, num_cus, reserved, st});
+    if (!hooked) { hooked = true; atexit(&MaskedStreamPool::at_exit); }
   }
 };
 static MaskedStreamPool g_masked_streams;
+void MaskedStreamPool::at_exit() {
+  std::lock_guard<std::mutex> lk(g_masked_streams.mu);
+  for (const Entry& e : g_masked_streams.idle) {
+    if (hipSetDevice(e.device) != hipSuccess) continue;
+    (void)hipStreamSynchronize(e.st);
+    (void)hipStreamDestroy(e.st);
+  }
+  g_masked_streams.idle.clear();
+}
 
 struct FilterBase {
   std::string err;
