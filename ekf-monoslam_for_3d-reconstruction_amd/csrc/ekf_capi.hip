@@ -375,7 +375,8 @@ struct Filter : FilterBase {
     mark("streams");
     if (own_stream && stream) hipStreamDestroy(stream);
     mark("stream b");
-    if (stream_b && stream_b_masked) g_masked_streams.give(device, num_cus, stream_b_reserved, stream_b);
+    const char* pool_env = getenv("EKF_MASKED_STREAM_POOL");        // =0: destroy it, as rounds 1-5 did (A/B; can stall, see the pool)
+    if (stream_b && stream_b_masked && !(pool_env && atoi(pool_env) == 0)) g_masked_streams.give(device, num_cus, stream_b_reserved, stream_b);
     else if (stream_b) hipStreamDestroy(stream_b);
     mark("stream g");
     if (stream_g) hipStreamDestroy(stream_g);
